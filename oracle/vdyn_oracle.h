@@ -1,0 +1,55 @@
+/*
+ * ORACLE -- test infrastructure, NOT product code.
+ *
+ * CPU restatement of the reference's RK4 / Pacejka hot path
+ * (/root/reference/libs/vehicle_model/vehicle_model.py:220-445), used only as
+ * the checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg.  Nothing under python-motionplanning_amd/ may include, link or load it.
+ *
+ * Parity pinning: validated against golden vectors produced by importing the
+ * reference itself in the build container (tests/golden/generate_golden.py,
+ * tests/test_oracle_golden.py).  The reference has no tests of its own.
+ */
+#ifndef VDYN_ORACLE_H
+#define VDYN_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same fields as VehicleParameters (vehicle_model.py:17-61) that the path reads,
+ * plus g (vehicle_model.py:230).  Pacejka D is NOT here: the reference
+ * overwrites it with mu_max on every call (vehicle_model.py:232-235). */
+typedef struct OracleParams {
+    double m, a, b, Izz, Jw, hg, T, wL, wR, rw, g;
+    double B[4], C[4]; /* FL, FR, RL, RR */
+} OracleParams;
+
+#define ORACLE_DECL(S, REAL)                                                                   \
+    void oracle_planar_model_##S(const OracleParams *p, const REAL *state,                     \
+                                 const REAL *tire_torques, const REAL *mu_max,                 \
+                                 const REAL *delta, REAL ax_prev, REAL ay_prev,                \
+                                 REAL *state_dot, REAL *aux, REAL *outputs, REAL *acc);        \
+    void oracle_planar_model_RK4_##S(const OracleParams *p, double dt, const REAL *state,      \
+                                     const REAL *tire_torques, const REAL *mu_max,             \
+                                     const REAL *delta, REAL ax_prev, REAL ay_prev,            \
+                                     REAL *state_update, REAL *state_dot, REAL *outputs,       \
+                                     REAL *acc);                                               \
+    int oracle_rollout_##S(const OracleParams *p, long n, int H, double dt,                    \
+                           const REAL *state0, const REAL *ctrl, int k, int layout,            \
+                           const int *path_id, int P, const double *mu4, REAL *terminal,       \
+                           REAL *traj, int traj_stride, int nthreads);                         \
+    int oracle_mpc_argmin_##S(const OracleParams *p, int E, int C, int H, double dt,           \
+                              const REAL *ego, const REAL *cand, const REAL *goal,             \
+                              REAL w_delta, REAL *best_cost, int *best_idx, REAL *cost_all,    \
+                              int nthreads);
+
+ORACLE_DECL(f64, double)
+ORACLE_DECL(f32, float)
+
+int oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

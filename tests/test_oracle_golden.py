@@ -1,0 +1,181 @@
+"""CPU: pin the oracle (oracle/) against golden vectors produced by importing
+the reference (tests/golden/generate_golden.py).  The oracle restates
+vehicle_model.py:220-445 operation for operation, so fp64 agreement is at
+rounding level (libm vs NumPy's sin/cos/atan kernels differ by <= 1 ulp)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+TOL = 1e-12  # relative, vs the magnitude of each quantity's row
+
+
+def close(a, b, tol=TOL, scale=None):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    s = np.maximum(np.abs(b), 1.0 if scale is None else scale)
+    err = np.max(np.abs(a - b) / s)
+    assert err <= tol, err
+
+
+def test_kat1_bit_exact(oracle):
+    """KAT-1 of SURVEY.md section 8a, measured on the reference."""
+    p = oracle.default_params()
+    s = [25, 0, 0] + [25 / p.rw] * 4 + [0, 0, 0]
+    o = oracle.planar_model_RK4(p, 1e-4, s, [0] * 4, [1] * 4, [0.02, 0.02, 0, 0], 0, 0)
+    want = [2.4999996979914723e+01, 2.9402126600312881e-04, 3.7460500999973191e-04,
+            8.1086421344188210e+01, 8.1086469091352370e+01, 8.1087243497252814e+01,
+            8.1087288891381220e+01, 1.8738250992909321e-08, 2.4999998502186231e-03,
+            1.4726234923492799e-08]
+    close(o[0], want, 1e-15)
+    assert abs(o[7] - -0.030200889513079934) < 1e-15
+    assert abs(o[8] - 2.944897222404597) < 1e-14
+    assert abs(p.rw - 0.308309813617345) < 1e-15
+    assert abs(p.Izz - 1948.2304506781593) < 1e-9
+
+
+def test_g1_step_kats(oracle):
+    g = load_golden("g1_step_kat.npz")
+    p = oracle.default_params()
+    for i in range(len(g["state"])):
+        o = oracle.planar_model_RK4(p, float(g["dt"]), g["state"][i], g["torque"][i], g["mu"][i],
+                                    g["delta"][i], *g["ax_ay_prev"][i])
+        close(o[0], g["state_update"][i])
+        close([o[1], o[2], o[3], o[4]], g["xyyawU"][i])
+        close(o[5], g["state_dot"][i], scale=np.abs(g["state_dot"][i]).max())
+        close(o[6], g["outputs"][i], scale=np.abs(g["outputs"][i]).max())
+        close([o[7], o[8]], g["acc"][i])
+
+
+def test_g2_derivative(oracle):
+    g = load_golden("g2_deriv.npz")
+    p = oracle.default_params()
+    for i in range(len(g["state"])):
+        o = oracle.planar_model(p, g["state"][i], g["torque"][i], g["mu"][i], g["delta"][i],
+                                *g["ax_ay_prev"][i])
+        close(o[0], g["state_dot"][i], scale=np.abs(g["state_dot"][i]).max())
+        close(o[1:5], g["aux"][i])
+        close(o[5], g["outputs"][i], scale=np.abs(g["outputs"][i]).max())
+        close(o[6:8], g["acc"][i])
+
+
+@pytest.mark.parametrize("tag,dt", [("dt1e-4", 1e-4), ("dt1e-3", 1e-3)])
+def test_g3_rollouts_cfg2(oracle, tag, dt):
+    g = load_golden("g3_rollout_cfg2.npz")
+    p = oracle.default_params()
+    term, traj = oracle.rollout(p, g["state0"], g["ctrl"], dt, traj_stride=20, nthreads=4)
+    close(term, g["terminal_" + tag], 1e-10)
+    close(traj, g["every20_" + tag], 1e-10)
+
+
+@pytest.mark.parametrize("tag", ["world", "waypoints"])
+def test_g4_closed_loop_replay(oracle, tag):
+    """Every RK4 call the reference's Car.drive made in 3 frames (drive.py:141-143),
+    replayed call by call with the logged inputs."""
+    g = load_golden(f"g4_closed_loop_{tag}.npz")
+    p = oracle.default_params()
+    dt = float(g["dt"])
+    for i in range(len(g["state"])):
+        o = oracle.planar_model_RK4(p, dt, g["state"][i], g["torque"][i], g["mu"][i],
+                                    g["delta"][i], *g["ax_ay_prev"][i])
+        close(o[0], g["state_update"][i])
+        close(o[5], g["state_dot"][i], scale=np.abs(g["state_dot"][i]).max())
+        close(o[6], g["outputs"][i], scale=np.abs(g["outputs"][i]).max())
+        close([o[7], o[8]], g["acc"][i])
+    # and as one uninterrupted rollout with the logged zero-order-hold controls (k = 12)
+    n = len(g["state"])
+    ctrl = np.concatenate([g["delta"], g["torque"], g["mu"]], axis=1)[:, :, None]  # [H][12][1]
+    s0 = np.concatenate([g["state"][0], g["ax_ay_prev"][0]])[:, None]
+    term = oracle.rollout(p, s0, ctrl, dt)
+    close(term[:10, 0], g["state_update"][n - 1], 1e-11)
+    close(term[10:, 0], g["acc"][n - 1], 1e-9)
+
+
+def test_g5_quirks(oracle):
+    g = load_golden("g5_quirks.npz")
+    p = oracle.default_params()
+    H, dt = int(g["H"]), float(g["dt"])
+    for i, name in enumerate(g["names"]):
+        c12 = np.concatenate([g["delta"][i], g["torque"][i], g["mu"][i]])
+        ctrl = np.broadcast_to(c12[None, :, None], (H, 12, 1))
+        term = oracle.rollout(p, g["state0"][i][:, None], ctrl, dt)[:, 0]
+        o = oracle.planar_model_RK4(p, dt, g["state0"][i][:10], g["torque"][i], g["mu"][i],
+                                    g["delta"][i], g["state0"][i][10], g["state0"][i][11])
+        first = np.concatenate([o[0], [o[7], o[8]], o[5], o[6]])
+        f_ref = g["first_step"][i]
+        close(first[:12], f_ref[:12], 1e-12), name
+        close(first[12:22], f_ref[12:22], 1e-12, scale=np.abs(f_ref[12:22]).max())
+        close(first[22:], f_ref[22:], 1e-12, scale=np.abs(f_ref[22:]).max())
+        close(term, g["terminal"][i], 1e-10)
+
+
+def test_g5_zero_slip_takes_fallback_branch(oracle):
+    """Quirk Q5: combined slip exactly 0 -> vehicle_model.py:311-348 fallback."""
+    g = load_golden("g5_quirks.npz")
+    i = list(g["names"]).index("Q5_zero_slip")
+    p = oracle.default_params()
+    o = oracle.planar_model(p, g["state0"][i][:10], g["torque"][i], g["mu"][i], g["delta"][i], 0, 0)
+    assert o[5][12] == 0.0 and o[5][15] == 0.0          # s_FL, s_RR
+    assert np.all(np.isfinite(o[0])) and np.all(o[5][:8] == 0.0)
+
+
+def test_g6_float32_floor(oracle):
+    """Informational fp32 floor: the reference fed float32 arrays vs the float
+    instantiation of the oracle (libm sinf/atanf vs NumPy's float32 kernels
+    differ in the last ulp, which the 200-step recurrence amplifies)."""
+    g3 = load_golden("g3_rollout_cfg2.npz")
+    g6 = load_golden("g6_ref_float32.npz")
+    p = oracle.default_params()
+    for tag, dt in (("dt1e-4", 1e-4), ("dt1e-3", 1e-3)):
+        term = oracle.rollout(p, g3["state0"].astype(np.float32), g3["ctrl"].astype(np.float32), dt)
+        assert term.dtype == np.float32
+        close(term, g6["terminal_" + tag], 1e-3)
+        close(term, g3["terminal_" + tag], 1e-3)         # and vs the fp64 reference
+
+
+def test_g7_mpc(oracle):
+    g = load_golden("g7_mpc.npz")
+    p = oracle.default_params()
+    ego, cand, goal = (g[k].astype(np.float64) for k in ("ego", "cand", "goal"))
+    bc, bi, cost = oracle.mpc_argmin(p, ego, cand, goal, float(g["dt"]), float(g["w_delta"]),
+                                     return_costs=True)
+    close(cost, g["cost"], 1e-10)
+    assert np.array_equal(bi, g["best_idx"])
+    close(bc, g["best_cost"], 1e-10)
+    # terminal states of all E*C rollouts through the generic rollout entry
+    E, C = ego.shape[1], cand.shape[2]
+    s0 = np.repeat(ego, C, axis=1)
+    ctrl = np.tile(cand, (1, 1, E))
+    term = oracle.rollout(p, s0, ctrl, float(g["dt"]))
+    close(term.reshape(12, E, C), g["terminal"], 1e-10)
+
+
+def test_g8_rollouts_cfg3_shared_controls(oracle, workloads):
+    g = load_golden("g8_rollout_cfg3.npz")
+    p = oracle.default_params()
+    s0, tab = g["state0"].astype(np.float64), g["table"].astype(np.float64)
+    term, traj = oracle.rollout(p, s0, tab, float(g["dt"]), path_id=g["path_id"], traj_stride=50)
+    close(term, g["terminal"], 1e-10)
+    close(traj, g["every50"], 1e-10)
+    # shared table == expanded per-rollout controls, bit for bit
+    term2 = oracle.rollout(p, s0, workloads.expand_shared_controls(tab, g["path_id"]), float(g["dt"]))
+    assert np.array_equal(term, term2)
+
+
+def test_threads_do_not_change_results(oracle, workloads):
+    p = oracle.default_params()
+    s0, ctrl = workloads.config2(8, 30)
+    a = oracle.rollout(p, s0, ctrl, 1e-3, nthreads=1)
+    b = oracle.rollout(p, s0, ctrl, 1e-3, nthreads=4)
+    assert np.array_equal(a, b)
+
+
+def test_empty_and_bad_inputs(oracle):
+    p = oracle.default_params()
+    term = oracle.rollout(p, np.zeros((12, 0)), np.zeros((5, 2, 0)), 1e-3)
+    assert term.shape == (12, 0)
+    with pytest.raises(ValueError):
+        oracle.rollout(p, np.zeros((10, 3)), np.zeros((5, 2, 3)), 1e-3)
+    with pytest.raises(ValueError):
+        oracle.rollout(p, np.zeros((12, 3)), np.zeros((5, 3, 3)), 1e-3)
+    with pytest.raises(ValueError):
+        oracle.rollout(p, np.zeros((12, 3)), np.zeros((2, 5, 2)), 1e-3, path_id=[0, 1, 2])
