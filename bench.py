@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- RK4 vehicle-steps/s of the HIP rollout kernel on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: ONE launch of the rollout
+kernel over BASELINE.json configs[2] -- 65536 rollouts (9363 egos x 7 lattice
+paths) x 200 RK4 steps, fp32, dt = 1e-3, per-path controls shared through LDS --
+on every GPU (weak scaling: each rank integrates its own 65536-rollout slice of a
+world*65536 workload), followed for N > 1 by the RCCL all-gather of the terminal
+states, which is the only exchange the path has.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_PER_GPU = 65536
+HORIZON = 200
+DT = 1e-3
+# SURVEY.md section 8(d) contract figures (also DESIGN.md section 5)
+BYTES_PER_STEP_SHARED = 96.0 / HORIZON          # (12 in + 12 out) * 4 B / H, controls from LDS
+BYTES_PER_STEP_PER_ROLLOUT = 8.0 + 96.0 / HORIZON
+FLOP_PER_STEP = 850.0
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3                        # fp32 vector peak (= fp32 MFMA peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations")
+    return ap.parse_args()
+
+
+def timed_launches(fn, n, torch):
+    """Average duration (s) of n launches of fn(), HIP events on the launching stream."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+
+
+def cpu_baseline(W):
+    """The oracle (oracle/, the checker -- never the product) timed on this host:
+    kind 'port'.  Sample: the first 16384 rollouts x 200 steps of the bench workload."""
+    from oracle import oracle as O
+    O.build()
+    p = O.default_params()
+    n = 16384
+    s0, tab, pid = W.config3(n, HORIZON, np.float32)
+    s0, tab = s0.astype(np.float64), tab.astype(np.float64)
+    threads = O.max_threads()
+    O.rollout(p, s0[:, :256], tab, DT, path_id=pid[:256], nthreads=threads)  # warm
+    t0 = time.perf_counter()
+    O.rollout(p, s0, tab, DT, path_id=pid, nthreads=threads)
+    t_all = time.perf_counter() - t0
+    n1 = 2048
+    t0 = time.perf_counter()
+    O.rollout(p, s0[:, :n1], tab, DT, path_id=pid[:n1], nthreads=1)
+    t_one = time.perf_counter() - t0
+    return {
+        "value": n * HORIZON / t_all, "unit": "vehicle-steps/s", "cores": threads, "kind": "port",
+        "sample": f"{n} rollouts x {HORIZON} steps of the bench workload, fp64 C oracle, OpenMP "
+                  f"{threads} threads ({t_all:.2f} s); 1 thread on {n1} rollouts: "
+                  f"{n1 * HORIZON / t_one:.3e} steps/s",
+        "value_1core": n1 * HORIZON / t_one,
+        "reference_python_1core": 4.04e3,  # measured in the build container only
+    }
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+    (profiles/pmc_summary.json, written by profiles/collect.sh), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("python-motionplanning_amd")
+    W = pkg.workloads
+    vm = pkg.VehicleModel(2.906, np.deg2rad(30), DT, device=local_rank)
+
+    # workload: world * 65536 rollouts, this rank's contiguous 65536-slice, resident in HBM
+    s0_all, tab, pid_all = W.config3(N_PER_GPU * world, HORIZON, np.float32)
+    lo, hi = rank * N_PER_GPU, (rank + 1) * N_PER_GPU
+    s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
+    pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
+    tabd = torch.from_numpy(tab).to(dev)
+    gathered = torch.empty((world, 12, N_PER_GPU), dtype=torch.float32, device=dev) if world > 1 else None
+    del s0_all, pid_all
+
+    kern_ev = []
+
+    def step(record):
+        if record:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        term = vm.rollout(s0, tabd, path_id=pid)
+        if record:
+            b.record()
+            kern_ev.append((a, b))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, term)
+        return term
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        term = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(term).all()), "non-finite terminal states"
+
+    kern_s = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) * 1e-3
+    units = world * N_PER_GPU * HORIZON * args.steps
+    steps_per_launch = N_PER_GPU * HORIZON
+    out = {
+        "metric": "RK4 vehicle-steps/sec", "value": units / elapsed, "unit": "vehicle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rollouts_per_s": world * N_PER_GPU * args.steps / elapsed,
+        "config": {
+            "workload": "BASELINE configs[2]: 65536 rollouts per GPU (ego r//7, lattice path r%7) x 200 "
+                        "RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared via LDS; "
+                        "N>1: + RCCL all-gather of terminal states [12][65536] per rank",
+            "rollouts_per_gpu": N_PER_GPU, "horizon": HORIZON, "dt": DT, "controls": "shared[7][200][2]",
+        },
+    }
+    if rank == 0:
+        algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * N_PER_GPU
+        ach = algo_bytes / kern_s / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+            "kernel": "rollout_kernel<float,2,LDS-shared>", "kernel_ms": kern_s * 1e3,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "note": "register-resident scalar-nonlinear kernel: HBM and MFMA are both idle by design; "
+                    "the binding resource is VALU issue (roofline_valu)",
+        }
+        tf = FLOP_PER_STEP * steps_per_launch / kern_s / 1e12
+        out["roofline_valu"] = {
+            "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / VALU_PEAK_TFLOPS, "flop_per_vehicle_step": FLOP_PER_STEP,
+            "kernel_steps_per_s": steps_per_launch / kern_s,
+        }
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_configs(vm, W, torch, dev, s0, tab, pid)
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(W)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_configs(vm, W, torch, dev, s0, tab, pid):
+    """Secondary numbers (outside the timed region): per-rollout controls (the variant
+    with real HBM traffic), configs[1] fp64, configs[4] MPC argmin."""
+    ex = {}
+    ctrl = torch.from_numpy(W.expand_shared_controls(tab, pid.cpu().numpy())).to(dev)
+    vm.rollout(s0, ctrl)
+    t = timed_launches(lambda: vm.rollout(s0, ctrl), 5, torch)
+    n = N_PER_GPU * HORIZON
+    ex["per_rollout_controls_f32"] = {
+        "steps_per_s": n / t, "kernel_ms": t * 1e3,
+        "hbm_GBs_algorithmic": BYTES_PER_STEP_PER_ROLLOUT * n / t / 1e9,
+        "hbm_frac": BYTES_PER_STEP_PER_ROLLOUT * n / t / 1e9 / HBM_PEAK_GBS}
+    del ctrl
+    s2, c2 = W.config2(64, HORIZON)
+    s2d, c2d = torch.from_numpy(s2).to(dev), torch.from_numpy(c2).to(dev)
+    vm.rollout(s2d, c2d)
+    t = timed_launches(lambda: vm.rollout(s2d, c2d), 5, torch)
+    ex["config2_4096x200_f64"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
+    E, C, H = 1024, 512, 50
+    ego, cand, goal = (torch.from_numpy(a).to(dev) for a in W.config5(E, C, H))
+    vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA)
+    t = timed_launches(lambda: vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA), 5, torch)
+    ex["config5_mpc_1024x512x50_f32"] = {"steps_per_s": E * C * H / t, "kernel_ms": t * 1e3,
+                                         "rollouts_per_s": E * C / t}
+    # occupancy sweep of the main kernel: where the chip fills up
+    sweep = {}
+    for mult in (2, 4, 8):
+        sN, tabN, pidN = W.config3(N_PER_GPU * mult, HORIZON, np.float32)
+        a, b, c = (torch.from_numpy(x).to(dev) for x in (sN, tabN, pidN))
+        vm.rollout(a, b, path_id=c)
+        t = timed_launches(lambda: vm.rollout(a, b, path_id=c), 3, torch)
+        sweep[str(N_PER_GPU * mult)] = N_PER_GPU * mult * HORIZON / t
+    ex["steps_per_s_vs_rollouts_f32"] = sweep
+    return ex
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * vdyn.h -- C ABI of libvdyn_hip.so: MI355X (gfx950) batched 7-DoF planar
+ * vehicle model with Pacejka tires and its RK4 step.
+ *
+ * This is the drop-in boundary for ONE hot path of earasteh/Python-Motionplanning:
+ *
+ *   libs/vehicle_model/vehicle_model.py:220-425  VehicleModel.planar_model
+ *   libs/vehicle_model/vehicle_model.py:427-445  VehicleModel.planar_model_RK4
+ *   libs/vehicle_model/drive.py:141-143          the caller (zero-order-hold loop)
+ *
+ * The reference is pure Python, so "what its FFI would bind" is a ctypes
+ * binding of these symbols (INTEGRATION.md shows the stub).  Plain pointers and
+ * sizes only; no exceptions cross the ABI; every function returns VDYN_OK (0)
+ * or a negative VDYN_ERR_* code, with text from vdyn_last_error().
+ *
+ * Data layout (all arrays contiguous, struct-of-arrays over rollouts):
+ *   state   [10][N]  rows U, V, wz, wFL, wFR, wRL, wRR, yaw, x, y  (vehicle_model.py:224)
+ *   state12 [12][N]  the 10 rows above + ax_prev, ay_prev: the two body
+ *                    accelerations the caller carries step to step
+ *                    (vehicle_model.py:255-258,442-443; drive.py:141)
+ *   ctrl, k = 12     rows delta FL,FR,RL,RR | tire_torques FL..RR | mu_max FL..RR
+ *                    (the three 4-vectors of vehicle_model.py:225-227)
+ *   ctrl, k = 2      rows delta_front, torque_all: expands to delta=[d,d,0,0],
+ *                    tire_torques=[t,t,t,t], mu_max = mu4 (NULL -> [1,1,1,1]),
+ *                    i.e. exactly the call of drive.py:142-143
+ *   outputs [18][N]  Fx x4, Fy x4, Fz x4, s x4, FxtFL, FytFL (vehicle_model.py:420-423)
+ *
+ * `_dev` entry points take DEVICE pointers, enqueue on `stream` (a hipStream_t
+ * passed as void*; NULL = the default stream) and return without synchronising.
+ * `_host` entry points take HOST pointers, stage through the handle's device
+ * scratch and return after the results are in the caller's buffers.
+ * The caller owns every buffer; the library never frees caller memory and never
+ * writes an input.  A handle is not thread-safe; distinct handles are independent.
+ * Non-finite values propagate as in the reference (vx = 0 divides by zero,
+ * vehicle_model.py:284-293); there is no clamping.
+ */
+#ifndef VDYN_H
+#define VDYN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDYN_ABI_VERSION 1
+
+enum {
+    VDYN_OK = 0,
+    VDYN_ERR_ARG = -1,    /* bad argument (null pointer, bad size / k / layout) */
+    VDYN_ERR_HIP = -2,    /* a HIP runtime call failed                          */
+    VDYN_ERR_NODEV = -3,  /* no usable gfx950 device                            */
+    VDYN_ERR_OOM = -4     /* device or host allocation failed                   */
+};
+
+enum {
+    VDYN_CTRL_PER_ROLLOUT = 0, /* ctrl is [H][k][N], time-major                       */
+    VDYN_CTRL_SHARED = 1       /* ctrl is a table [P][H][k] + path_id[N] (staged in LDS) */
+};
+
+/* Replaces: class VehicleParameters, vehicle_model.py:17-61 (the fields the path
+ * reads) + g = 9.81 (vehicle_model.py:230).  Pacejka D is deliberately absent:
+ * the reference overwrites it with mu_max on every call (vehicle_model.py:232-235),
+ * so mu_max is an explicit input here and parameters are never mutated. */
+typedef struct VdynParams {
+    double m, a, b, Izz, Jw, hg, T, wL, wR, rw, g;
+    double B[4], C[4]; /* Pacejka B, C for FL, FR, RL, RR (vehicle_model.py:41-54) */
+} VdynParams;
+
+typedef struct VdynHandle VdynHandle;
+
+int vdyn_abi_version(void);
+int vdyn_device_count(void);
+
+/* VehicleParameters() with its default arguments (vehicle_model.py:18-22). */
+void vdyn_params_default(VdynParams *p);
+
+/* Replaces: VehicleModel.__init__ (vehicle_model.py:69-95) as far as the path
+ * needs it -- dt is per call here.  Copies *p.  device = HIP device ordinal. */
+int vdyn_create(const VdynParams *p, int device, VdynHandle **out);
+int vdyn_set_params(VdynHandle *h, const VdynParams *p);
+void vdyn_destroy(VdynHandle *h);
+/* Text of the last error on this handle (h == NULL: of the last failed vdyn_create). */
+const char *vdyn_last_error(const VdynHandle *h);
+/* hipStreamSynchronize(stream) for callers that have no HIP binding of their own. */
+int vdyn_stream_synchronize(VdynHandle *h, void *stream);
+
+/* ---- planar_model: one derivative evaluation, vehicle_model.py:220-425 -------------
+ * state [10][n], ctrl12 [12][n], acc_prev [2][n] (ax_prev, ay_prev)
+ * -> state_dot [10][n], aux [4][n] = vx, vy, ax, ay (:410-416; nullable),
+ *    outputs [18][n] (nullable), acc [2][n] = axc, ayc (:413-414).                     */
+int vdyn_planar_model_f64_dev(VdynHandle *h, int64_t n, const double *state, const double *ctrl12,
+                              const double *acc_prev, double *state_dot, double *aux,
+                              double *outputs, double *acc, void *stream);
+int vdyn_planar_model_f32_dev(VdynHandle *h, int64_t n, const float *state, const float *ctrl12,
+                              const float *acc_prev, float *state_dot, float *aux,
+                              float *outputs, float *acc, void *stream);
+int vdyn_planar_model_f64_host(VdynHandle *h, int64_t n, const double *state, const double *ctrl12,
+                               const double *acc_prev, double *state_dot, double *aux,
+                               double *outputs, double *acc);
+int vdyn_planar_model_f32_host(VdynHandle *h, int64_t n, const float *state, const float *ctrl12,
+                               const float *acc_prev, float *state_dot, float *aux,
+                               float *outputs, float *acc);
+
+/* ---- planar_model_RK4: one RK4 step, vehicle_model.py:427-445 ----------------------
+ * state_in [12][n], ctrl [k][n] (k = 2 or 12), dt = VehicleModel.dt (:428)
+ * -> state_out [12][n] (rows 10, 11 = RK4-averaged axc, ayc, :442-443; may alias
+ *    state_in), state_dot [10][n] (:440; nullable), outputs [18][n] (:441; nullable).  */
+int vdyn_step_f64_dev(VdynHandle *h, int64_t n, const double *state_in, const double *ctrl, int k,
+                      double dt, const double *mu4, double *state_out, double *state_dot,
+                      double *outputs, void *stream);
+int vdyn_step_f32_dev(VdynHandle *h, int64_t n, const float *state_in, const float *ctrl, int k,
+                      double dt, const double *mu4, float *state_out, float *state_dot,
+                      float *outputs, void *stream);
+int vdyn_step_f64_host(VdynHandle *h, int64_t n, const double *state_in, const double *ctrl, int k,
+                       double dt, const double *mu4, double *state_out, double *state_dot,
+                       double *outputs);
+int vdyn_step_f32_host(VdynHandle *h, int64_t n, const float *state_in, const float *ctrl, int k,
+                       double dt, const double *mu4, float *state_out, float *state_dot,
+                       float *outputs);
+
+/* ---- rollout: H RK4 steps in ONE launch, the loop of drive.py:114,141-143 -----------
+ * state0 [12][n]; ctrl per `layout` (VDYN_CTRL_*): [H][k][n], or table [P][H][k]
+ * with path_id [n] (values in [0,P)); mu4 = 4 host doubles used when k = 2 (NULL -> 1).
+ * -> terminal [12][n]; traj (nullable) [H / traj_stride][12][n] = the state after
+ *    steps traj_stride, 2*traj_stride, ...                                             */
+int vdyn_rollout_f64_dev(VdynHandle *h, int64_t n, int32_t H, const double *state0,
+                         const double *ctrl, int k, int layout, const int32_t *path_id, int32_t P,
+                         double dt, const double *mu4, double *terminal, double *traj,
+                         int32_t traj_stride, void *stream);
+int vdyn_rollout_f32_dev(VdynHandle *h, int64_t n, int32_t H, const float *state0,
+                         const float *ctrl, int k, int layout, const int32_t *path_id, int32_t P,
+                         double dt, const double *mu4, float *terminal, float *traj,
+                         int32_t traj_stride, void *stream);
+int vdyn_rollout_f64_host(VdynHandle *h, int64_t n, int32_t H, const double *state0,
+                          const double *ctrl, int k, int layout, const int32_t *path_id, int32_t P,
+                          double dt, const double *mu4, double *terminal, double *traj,
+                          int32_t traj_stride);
+int vdyn_rollout_f32_host(VdynHandle *h, int64_t n, int32_t H, const float *state0,
+                          const float *ctrl, int k, int layout, const int32_t *path_id, int32_t P,
+                          double dt, const double *mu4, float *terminal, float *traj,
+                          int32_t traj_stride);
+
+/* ---- MPC selection (BASELINE config 5): E egos x C shared candidates x H steps -------
+ * Rollout (e, c) starts from ego e and applies candidate c's k = 2 controls.
+ *   cost[e][c] = ||(x_T, y_T) - goal_e||_2 + w_delta * sum_t delta[t][c]^2
+ * (terminal-distance score after collision_checker.py:175).  Candidates whose cost
+ * is not finite are disqualified (collision_checker.py:190-191); the winner is the
+ * lowest cost, lowest index on ties (strict '<' scan, :194-196); no finite
+ * candidate -> best_idx = -1, best_cost = +inf (best_index = None, :163).
+ * ego [12][E], cand [H][2][C], goal [2][E]
+ * -> best_cost [E], best_idx [E], cost_all (nullable) [E][C].                           */
+int vdyn_mpc_argmin_f32_dev(VdynHandle *h, int32_t E, int32_t C, int32_t H, const float *ego,
+                            const float *cand, const float *goal, double dt, double w_delta,
+                            float *best_cost, int32_t *best_idx, float *cost_all, void *stream);
+int vdyn_mpc_argmin_f64_dev(VdynHandle *h, int32_t E, int32_t C, int32_t H, const double *ego,
+                            const double *cand, const double *goal, double dt, double w_delta,
+                            double *best_cost, int32_t *best_idx, double *cost_all, void *stream);
+int vdyn_mpc_argmin_f32_host(VdynHandle *h, int32_t E, int32_t C, int32_t H, const float *ego,
+                             const float *cand, const float *goal, double dt, double w_delta,
+                             float *best_cost, int32_t *best_idx, float *cost_all);
+int vdyn_mpc_argmin_f64_host(VdynHandle *h, int32_t E, int32_t C, int32_t H, const double *ego,
+                             const double *cand, const double *goal, double dt, double w_delta,
+                             double *best_cost, int32_t *best_idx, double *cost_all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDYN_H */

@@ -1,0 +1,55 @@
+"""Build recipe of ``libvdyn_hip.so`` (explicit hipcc, in-tree, gfx950 only).
+
+``python -m python_motionplanning_amd._build`` or ``__graft_entry__.build()``.
+hipcc cross-compiles without a GPU; the built library is git-ignored but
+travels to the GPU box with the working tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libvdyn_hip.so")
+SOURCES = ["vdyn_kernels.hip", "vdyn_capi.hip"]
+HEADERS = [os.path.join(CSRC, "vdyn_device.hpp"), os.path.join(CSRC, "vdyn_internal.hpp"),
+           os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source of the package into libvdyn_hip.so."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", LIB_PATH + ".tmp",
+           *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,439 @@
+// vdyn_capi.hip -- the C ABI of include/vdyn.h: handle, argument checks, the
+// `_dev` entry points (enqueue on the caller's stream) and the `_host` entry
+// points (stage through pinned + device scratch owned by the handle).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vdyn_internal.hpp"
+
+struct VdynHandle {
+    int device = 0;
+    VdynParams p{};
+    std::string err;
+    hipStream_t stream = nullptr;   // used by the _host entry points
+    void *d_scratch = nullptr;
+    size_t d_bytes = 0;
+    void *h_pinned = nullptr;
+    size_t h_bytes = 0;
+
+    int fail(int code, const std::string &msg)
+    {
+        err = msg;
+        return code;
+    }
+    int fail_hip(const char *what, hipError_t e)
+    {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return VDYN_ERR_HIP;
+    }
+};
+
+static std::string g_create_error;
+
+#define VDYN_HIP(h, expr)                                        \
+    do {                                                         \
+        hipError_t e_ = (expr);                                  \
+        if (e_ != hipSuccess) return (h)->fail_hip(#expr, e_);   \
+    } while (0)
+
+static bool params_ok(const VdynParams *p, std::string *why)
+{
+    const double v[] = {p->m, p->a, p->b, p->Izz, p->Jw, p->hg, p->T, p->wL, p->wR, p->rw, p->g};
+    for (double x : v)
+        if (!std::isfinite(x)) { *why = "VdynParams: non-finite field"; return false; }
+    if (!(p->m > 0) || !(p->Izz > 0) || !(p->Jw > 0)) { *why = "VdynParams: m, Izz, Jw must be > 0"; return false; }
+    if (!(p->a + p->b > 0) || !(p->wL + p->wR > 0)) { *why = "VdynParams: a+b and wL+wR must be > 0"; return false; }
+    for (int i = 0; i < 4; ++i)
+        if (!std::isfinite(p->B[i]) || !std::isfinite(p->C[i])) { *why = "VdynParams: non-finite Pacejka B/C"; return false; }
+    return true;
+}
+
+extern "C" {
+
+int vdyn_abi_version(void) { return VDYN_ABI_VERSION; }
+
+int vdyn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void vdyn_params_default(VdynParams *p)
+{
+    if (!p) return;
+    // VehicleParameters.__init__ defaults, vehicle_model.py:18-61
+    const double mf = 987.89, mr = 869.93, mus = 50, L = 2.906, ab_ratio = 0.85, T = 1.536;
+    const double hg = 0.55419, Jw = 1, kf = 26290, rr = 0.329;
+    p->m = mf + mr;
+    p->b = L / (1 + ab_ratio);
+    p->a = L - p->b;
+    p->Izz = 0.5 * p->m * p->a * p->b;
+    p->Jw = Jw;
+    p->hg = hg;
+    p->T = T;
+    p->wL = T / 2;
+    p->wR = T / 2;
+    p->rw = rr - (mf / 2 + mus) / kf;
+    p->g = 9.81;
+    for (int i = 0; i < 4; ++i) {
+        p->B[i] = 20.6357;
+        p->C[i] = 1.5047;
+    }
+}
+
+int vdyn_create(const VdynParams *p, int device, VdynHandle **out)
+{
+    if (!p || !out) { g_create_error = "vdyn_create: null argument"; return VDYN_ERR_ARG; }
+    *out = nullptr;
+    std::string why;
+    if (!params_ok(p, &why)) { g_create_error = why; return VDYN_ERR_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("vdyn_create: no HIP device (") + hipGetErrorString(e) + ")";
+        return VDYN_ERR_NODEV;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "vdyn_create: device ordinal out of range"; return VDYN_ERR_ARG; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return VDYN_ERR_HIP;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("vdyn_create: device is ") + prop.gcnArchName +
+                         ", this library carries gfx950 code only";
+        return VDYN_ERR_NODEV;
+    }
+    VdynHandle *h = new (std::nothrow) VdynHandle;
+    if (!h) { g_create_error = "vdyn_create: out of host memory"; return VDYN_ERR_OOM; }
+    h->device = device;
+    h->p = *p;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("vdyn_create: ") + hipGetErrorString(e);
+        delete h;
+        return VDYN_ERR_HIP;
+    }
+    *out = h;
+    return VDYN_OK;
+}
+
+int vdyn_set_params(VdynHandle *h, const VdynParams *p)
+{
+    if (!h || !p) return VDYN_ERR_ARG;
+    std::string why;
+    if (!params_ok(p, &why)) return h->fail(VDYN_ERR_ARG, why);
+    h->p = *p;
+    return VDYN_OK;
+}
+
+void vdyn_destroy(VdynHandle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    delete h;
+}
+
+const char *vdyn_last_error(const VdynHandle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int vdyn_stream_synchronize(VdynHandle *h, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    return VDYN_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------- _dev implementations --
+
+namespace {
+
+template <typename T>
+int planar_model_dev(VdynHandle *h, int64_t n, const T *state, const T *ctrl12, const T *acc_prev,
+                     T *state_dot, T *aux, T *outputs, T *acc, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (n < 0) return h->fail(VDYN_ERR_ARG, "planar_model: n < 0");
+    if (n == 0) return VDYN_OK;
+    if (!state || !ctrl12 || !acc_prev || !state_dot || !acc)
+        return h->fail(VDYN_ERR_ARG, "planar_model: null state / ctrl12 / acc_prev / state_dot / acc");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_planar_model<T>(h->p, n, state, ctrl12, acc_prev, state_dot, aux, outputs,
+                                             acc, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, const char *who)
+{
+    if (!h) return VDYN_ERR_ARG;
+    const std::string w(who);
+    if (a.n < 0 || a.H < 0) return h->fail(VDYN_ERR_ARG, w + ": n < 0 or H < 0");
+    if (a.k != 2 && a.k != 12) return h->fail(VDYN_ERR_ARG, w + ": k must be 2 or 12");
+    if (a.layout != VDYN_CTRL_PER_ROLLOUT && a.layout != VDYN_CTRL_SHARED)
+        return h->fail(VDYN_ERR_ARG, w + ": unknown control layout");
+    if (!std::isfinite(a.dt)) return h->fail(VDYN_ERR_ARG, w + ": dt is not finite");
+    if (a.n == 0) return VDYN_OK;
+    if (!a.state0 || !a.terminal) return h->fail(VDYN_ERR_ARG, w + ": null state buffer");
+    if (a.H > 0 && !a.ctrl) return h->fail(VDYN_ERR_ARG, w + ": null ctrl");
+    if (a.layout == VDYN_CTRL_SHARED && (!a.path_id || a.P <= 0))
+        return h->fail(VDYN_ERR_ARG, w + ": shared controls need path_id and P > 0");
+    if (a.traj && a.traj_stride <= 0) return h->fail(VDYN_ERR_ARG, w + ": traj needs traj_stride > 0");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, a, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int mpc_dev(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, const T *goal, double dt,
+            double w_delta, T *best_cost, int32_t *best_idx, T *cost_all, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (E < 0 || C <= 0 || H < 0) return h->fail(VDYN_ERR_ARG, "mpc_argmin: need E >= 0, C > 0, H >= 0");
+    if (!std::isfinite(dt)) return h->fail(VDYN_ERR_ARG, "mpc_argmin: dt is not finite");
+    if (E == 0) return VDYN_OK;
+    if (!ego || !goal || !best_cost || !best_idx || (H > 0 && !cand))
+        return h->fail(VDYN_ERR_ARG, "mpc_argmin: null buffer");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_mpc_argmin<T>(h->p, E, C, H, ego, cand, goal, dt, w_delta, best_cost,
+                                           best_idx, cost_all, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+// ---- host staging: [inputs | outputs] packed in one pinned buffer and one device
+// buffer, so a call costs one H2D copy, the kernel, one D2H copy.
+class Stage {
+public:
+    explicit Stage(VdynHandle *h) : h_(h) {}
+    // returns the byte offset of the region inside the staging buffers
+    size_t in(const void *src, size_t bytes) { return add(ins_, const_cast<void *>(src), bytes); }
+    size_t out(void *dst, size_t bytes) { return add(outs_, dst, bytes); }
+
+    int upload()
+    {
+        in_end_ = 0;
+        size_t off = 0;
+        for (auto &r : ins_) { r.off = off; off += round(r.bytes); }
+        in_end_ = off;
+        for (auto &r : outs_) { r.off = off; off += round(r.bytes); }
+        total_ = off;
+        VDYN_HIP(h_, hipSetDevice(h_->device));
+        if (total_ > h_->d_bytes) {
+            if (h_->d_scratch) { (void)hipFree(h_->d_scratch); h_->d_scratch = nullptr; h_->d_bytes = 0; }
+            if (hipMalloc(&h_->d_scratch, total_) != hipSuccess) return h_->fail(VDYN_ERR_OOM, "device scratch allocation failed");
+            h_->d_bytes = total_;
+        }
+        if (total_ > h_->h_bytes) {
+            if (h_->h_pinned) { (void)hipHostFree(h_->h_pinned); h_->h_pinned = nullptr; h_->h_bytes = 0; }
+            if (hipHostMalloc(&h_->h_pinned, total_, hipHostMallocDefault) != hipSuccess)
+                return h_->fail(VDYN_ERR_OOM, "pinned staging allocation failed");
+            h_->h_bytes = total_;
+        }
+        for (auto &r : ins_) std::memcpy((char *)h_->h_pinned + r.off, r.ptr, r.bytes);
+        if (in_end_ > 0)
+            VDYN_HIP(h_, hipMemcpyAsync(h_->d_scratch, h_->h_pinned, in_end_, hipMemcpyHostToDevice, h_->stream));
+        return VDYN_OK;
+    }
+    template <typename T> T *dev(size_t idx, bool is_out) const
+    {
+        const auto &r = (is_out ? outs_ : ins_)[idx];
+        return r.ptr ? reinterpret_cast<T *>((char *)h_->d_scratch + r.off) : nullptr;
+    }
+    int download()
+    {
+        if (total_ > in_end_)
+            VDYN_HIP(h_, hipMemcpyAsync((char *)h_->h_pinned + in_end_, (char *)h_->d_scratch + in_end_,
+                                        total_ - in_end_, hipMemcpyDeviceToHost, h_->stream));
+        VDYN_HIP(h_, hipStreamSynchronize(h_->stream));
+        for (auto &r : outs_)
+            if (r.ptr) std::memcpy(r.ptr, (char *)h_->h_pinned + r.off, r.bytes);
+        return VDYN_OK;
+    }
+
+private:
+    struct Region { void *ptr; size_t bytes; size_t off; };
+    static size_t round(size_t b) { return (b + 255) & ~(size_t)255; }
+    size_t add(std::vector<Region> &v, void *p, size_t bytes)
+    {
+        v.push_back({p, p ? bytes : 0, 0});
+        return v.size() - 1;
+    }
+    VdynHandle *h_;
+    std::vector<Region> ins_, outs_;
+    size_t in_end_ = 0, total_ = 0;
+};
+
+template <typename T>
+int planar_model_host(VdynHandle *h, int64_t n, const T *state, const T *ctrl12, const T *acc_prev,
+                      T *state_dot, T *aux, T *outputs, T *acc)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (n < 0) return h->fail(VDYN_ERR_ARG, "planar_model: n < 0");
+    if (n == 0) return VDYN_OK;
+    if (!state || !ctrl12 || !acc_prev || !state_dot || !acc)
+        return h->fail(VDYN_ERR_ARG, "planar_model: null state / ctrl12 / acc_prev / state_dot / acc");
+    const size_t e = sizeof(T) * (size_t)n;
+    Stage s(h);
+    const size_t i0 = s.in(state, 10 * e), i1 = s.in(ctrl12, 12 * e), i2 = s.in(acc_prev, 2 * e);
+    const size_t o0 = s.out(state_dot, 10 * e), o1 = s.out(aux, 4 * e), o2 = s.out(outputs, 18 * e),
+                 o3 = s.out(acc, 2 * e);
+    int rc = s.upload();
+    if (rc) return rc;
+    rc = planar_model_dev<T>(h, n, s.dev<T>(i0, false), s.dev<T>(i1, false), s.dev<T>(i2, false),
+                             s.dev<T>(o0, true), s.dev<T>(o1, true), s.dev<T>(o2, true), s.dev<T>(o3, true),
+                             h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+int rollout_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (a.n < 0 || a.H < 0 || (a.k != 2 && a.k != 12) ||
+        (a.layout != VDYN_CTRL_PER_ROLLOUT && a.layout != VDYN_CTRL_SHARED) ||
+        (a.layout == VDYN_CTRL_SHARED && a.P <= 0) || (a.traj && a.traj_stride <= 0))
+        return rollout_dev<T>(h, a, h->stream, who);  // reports the precise argument error
+    if (a.n == 0) return VDYN_OK;
+    if (!a.state0 || !a.terminal || (a.H > 0 && !a.ctrl) || (a.layout == VDYN_CTRL_SHARED && !a.path_id))
+        return h->fail(VDYN_ERR_ARG, std::string(who) + ": null buffer");
+    const size_t e = sizeof(T) * (size_t)a.n;
+    const size_t ctrl_bytes = a.layout == VDYN_CTRL_PER_ROLLOUT
+                                  ? (size_t)a.H * a.k * e
+                                  : sizeof(T) * (size_t)a.P * a.H * a.k;
+    Stage s(h);
+    const size_t i0 = s.in(a.state0, 12 * e), i1 = s.in(a.ctrl, ctrl_bytes),
+                 i2 = s.in(a.path_id, a.layout == VDYN_CTRL_SHARED ? sizeof(int32_t) * (size_t)a.n : 0);
+    const size_t o0 = s.out(a.terminal, 12 * e),
+                 o1 = s.out(a.traj, a.traj ? (size_t)(a.H / a.traj_stride) * 12 * e : 0),
+                 o2 = s.out(a.state_dot, 10 * e), o3 = s.out(a.outputs, 18 * e);
+    int rc = s.upload();
+    if (rc) return rc;
+    a.state0 = s.dev<T>(i0, false);
+    a.ctrl = s.dev<T>(i1, false);
+    a.path_id = s.dev<int>(i2, false);
+    a.terminal = s.dev<T>(o0, true);
+    a.traj = s.dev<T>(o1, true);
+    a.state_dot = s.dev<T>(o2, true);
+    a.outputs = s.dev<T>(o3, true);
+    rc = rollout_dev<T>(h, a, h->stream, who);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+int mpc_host(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, const T *goal, double dt,
+             double w_delta, T *best_cost, int32_t *best_idx, T *cost_all)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (E < 0 || C <= 0 || H < 0) return h->fail(VDYN_ERR_ARG, "mpc_argmin: need E >= 0, C > 0, H >= 0");
+    if (E == 0) return VDYN_OK;
+    if (!ego || !goal || !best_cost || !best_idx || (H > 0 && !cand))
+        return h->fail(VDYN_ERR_ARG, "mpc_argmin: null buffer");
+    Stage s(h);
+    const size_t i0 = s.in(ego, sizeof(T) * 12 * (size_t)E), i1 = s.in(cand, sizeof(T) * 2 * (size_t)H * C),
+                 i2 = s.in(goal, sizeof(T) * 2 * (size_t)E);
+    const size_t o0 = s.out(best_cost, sizeof(T) * (size_t)E), o1 = s.out(best_idx, sizeof(int32_t) * (size_t)E),
+                 o2 = s.out(cost_all, sizeof(T) * (size_t)E * C);
+    int rc = s.upload();
+    if (rc) return rc;
+    rc = mpc_dev<T>(h, E, C, H, s.dev<T>(i0, false), s.dev<T>(i1, false), s.dev<T>(i2, false), dt, w_delta,
+                    s.dev<T>(o0, true), s.dev<int32_t>(o1, true), s.dev<T>(o2, true), h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+vdyn::RolloutArgs<T> step_args(int64_t n, const T *state_in, const T *ctrl, int k, double dt,
+                               const double *mu4, T *state_out, T *state_dot, T *outputs)
+{
+    vdyn::RolloutArgs<T> a;
+    a.n = n; a.H = 1; a.state0 = state_in; a.ctrl = ctrl; a.k = k; a.layout = VDYN_CTRL_PER_ROLLOUT;
+    a.dt = dt; a.mu4 = mu4; a.terminal = state_out; a.state_dot = state_dot; a.outputs = outputs;
+    return a;
+}
+
+template <typename T>
+vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T *ctrl, int k, int layout,
+                                  const int32_t *path_id, int32_t P, double dt, const double *mu4,
+                                  T *terminal, T *traj, int32_t traj_stride)
+{
+    vdyn::RolloutArgs<T> a;
+    a.n = n; a.H = H; a.state0 = state0; a.ctrl = ctrl; a.k = k; a.layout = layout; a.path_id = path_id;
+    a.P = P; a.dt = dt; a.mu4 = mu4; a.terminal = terminal; a.traj = traj; a.traj_stride = traj_stride;
+    return a;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ extern "C" --------
+
+#define VDYN_DEFINE_ABI(S, T)                                                                            \
+    extern "C" int vdyn_planar_model_##S##_dev(VdynHandle *h, int64_t n, const T *state, const T *ctrl12, \
+                                               const T *acc_prev, T *state_dot, T *aux, T *outputs,     \
+                                               T *acc, void *stream)                                     \
+    {                                                                                                    \
+        return planar_model_dev<T>(h, n, state, ctrl12, acc_prev, state_dot, aux, outputs, acc, stream); \
+    }                                                                                                    \
+    extern "C" int vdyn_planar_model_##S##_host(VdynHandle *h, int64_t n, const T *state,               \
+                                                const T *ctrl12, const T *acc_prev, T *state_dot,       \
+                                                T *aux, T *outputs, T *acc)                              \
+    {                                                                                                    \
+        return planar_model_host<T>(h, n, state, ctrl12, acc_prev, state_dot, aux, outputs, acc);        \
+    }                                                                                                    \
+    extern "C" int vdyn_step_##S##_dev(VdynHandle *h, int64_t n, const T *state_in, const T *ctrl, int k, \
+                                       double dt, const double *mu4, T *state_out, T *state_dot,        \
+                                       T *outputs, void *stream)                                         \
+    {                                                                                                    \
+        return rollout_dev<T>(h, step_args<T>(n, state_in, ctrl, k, dt, mu4, state_out, state_dot, outputs), \
+                              stream, "step");                                                           \
+    }                                                                                                    \
+    extern "C" int vdyn_step_##S##_host(VdynHandle *h, int64_t n, const T *state_in, const T *ctrl, int k, \
+                                        double dt, const double *mu4, T *state_out, T *state_dot,       \
+                                        T *outputs)                                                      \
+    {                                                                                                    \
+        return rollout_host<T>(h, step_args<T>(n, state_in, ctrl, k, dt, mu4, state_out, state_dot, outputs), \
+                               "step");                                                                  \
+    }                                                                                                    \
+    extern "C" int vdyn_rollout_##S##_dev(VdynHandle *h, int64_t n, int32_t H, const T *state0,         \
+                                          const T *ctrl, int k, int layout, const int32_t *path_id,     \
+                                          int32_t P, double dt, const double *mu4, T *terminal, T *traj, \
+                                          int32_t traj_stride, void *stream)                             \
+    {                                                                                                    \
+        return rollout_dev<T>(h, rollout_args<T>(n, H, state0, ctrl, k, layout, path_id, P, dt, mu4,    \
+                                                 terminal, traj, traj_stride), stream, "rollout");       \
+    }                                                                                                    \
+    extern "C" int vdyn_rollout_##S##_host(VdynHandle *h, int64_t n, int32_t H, const T *state0,        \
+                                           const T *ctrl, int k, int layout, const int32_t *path_id,    \
+                                           int32_t P, double dt, const double *mu4, T *terminal,        \
+                                           T *traj, int32_t traj_stride)                                 \
+    {                                                                                                    \
+        return rollout_host<T>(h, rollout_args<T>(n, H, state0, ctrl, k, layout, path_id, P, dt, mu4,   \
+                                                  terminal, traj, traj_stride), "rollout");              \
+    }                                                                                                    \
+    extern "C" int vdyn_mpc_argmin_##S##_dev(VdynHandle *h, int32_t E, int32_t C, int32_t H, const T *ego, \
+                                             const T *cand, const T *goal, double dt, double w_delta,   \
+                                             T *best_cost, int32_t *best_idx, T *cost_all, void *stream) \
+    {                                                                                                    \
+        return mpc_dev<T>(h, E, C, H, ego, cand, goal, dt, w_delta, best_cost, best_idx, cost_all, stream); \
+    }                                                                                                    \
+    extern "C" int vdyn_mpc_argmin_##S##_host(VdynHandle *h, int32_t E, int32_t C, int32_t H,           \
+                                              const T *ego, const T *cand, const T *goal, double dt,    \
+                                              double w_delta, T *best_cost, int32_t *best_idx,          \
+                                              T *cost_all)                                               \
+    {                                                                                                    \
+        return mpc_host<T>(h, E, C, H, ego, cand, goal, dt, w_delta, best_cost, best_idx, cost_all);     \
+    }
+
+VDYN_DEFINE_ABI(f32, float)
+VDYN_DEFINE_ABI(f64, double)

@@ -1,0 +1,45 @@
+// vdyn_internal.hpp -- declarations shared by the kernel launchers
+// (vdyn_kernels.hip) and the C ABI (vdyn_capi.hip).  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "../../include/vdyn.h"
+
+namespace vdyn {
+
+template <typename T>
+struct RolloutArgs {
+    int64_t n = 0;
+    int H = 0;
+    const T *state0 = nullptr;   // [12][n]
+    const T *ctrl = nullptr;     // per layout
+    int k = 2;                   // 2 or 12
+    int layout = VDYN_CTRL_PER_ROLLOUT;
+    const int *path_id = nullptr;
+    int P = 0;
+    double dt = 0;
+    const double *mu4 = nullptr; // host, nullable
+    T *terminal = nullptr;       // [12][n]
+    T *traj = nullptr;           // nullable
+    int traj_stride = 0;
+    T *state_dot = nullptr;      // nullable, last step's RK4-averaged derivative [10][n]
+    T *outputs = nullptr;        // nullable, last step's RK4-averaged outputs   [18][n]
+};
+
+template <typename T>
+hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st);
+
+template <typename T>
+hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, const T *ctrl12,
+                               const T *acc_prev, T *state_dot, T *aux, T *outputs, T *acc,
+                               hipStream_t st);
+
+template <typename T>
+hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *ego, const T *cand,
+                             const T *goal, double dt, double w_delta, T *best_cost, int *best_idx,
+                             T *cost_all, hipStream_t st);
+
+}  // namespace vdyn

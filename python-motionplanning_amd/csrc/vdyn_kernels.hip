@@ -1,0 +1,319 @@
+// vdyn_kernels.hip -- gfx950 kernels of the batched RK4 / Pacejka path and their
+// launchers.  Mapping: one wavefront lane = one rollout; the 12 persistent
+// scalars of a rollout (10 states + ax_prev, ay_prev) stay in VGPRs for the
+// whole horizon; vehicle constants arrive as a by-value kernel argument and sit
+// in SGPRs; lattice-shared control tables are staged through LDS; per-rollout
+// controls are read time-major so that a wave reads 64 consecutive values.
+#include "vdyn_internal.hpp"
+#include "vdyn_device.hpp"
+
+namespace vdyn {
+
+constexpr int kBlock = 256;            // 4 waves: one per SIMD of a CU
+constexpr int kLdsBudget = 48 * 1024;  // bytes of control table staged per chunk
+
+// Controls of one step for lane r.
+//   LAYOUT 0: global [H][K][n]          (coalesced over r)
+//   LAYOUT 1: LDS chunk [tc][K][P]      (lane reads column path_id[r])
+//   LAYOUT 2: global table [P][H][K]    (gather; only when a step of the table exceeds the LDS budget)
+template <typename T, int K>
+struct Ctrl {
+    T delta[4], tq[4], mu[4];
+    __device__ __forceinline__ void set(const DevParams<T> &P, const T *c, int64_t stride)
+    {
+        if (K == 2) {
+            delta[0] = delta[1] = c[0];
+            delta[2] = delta[3] = T(0);
+            const T t = c[stride];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { tq[i] = t; mu[i] = P.mu[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                delta[i] = c[(int64_t)i * stride];
+                tq[i] = c[(int64_t)(4 + i) * stride];
+                mu[i] = c[(int64_t)(8 + i) * stride];
+            }
+        }
+    }
+};
+
+// H zero-order-hold RK4 steps per lane (the loop of drive.py:114,141-143 with
+// vehicle_model.py:427-445 inside).  DIAG additionally returns the last step's
+// state_dot / outputs (used for H = 1: the planar_model_RK4 drop-in).
+template <typename T, int K, int LAYOUT, bool DIAG>
+__global__ void __launch_bounds__(kBlock)
+rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
+               const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
+               T *__restrict__ terminal, T *__restrict__ traj, int traj_stride,
+               T *__restrict__ state_dot_out, T *__restrict__ outputs_out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *tab = reinterpret_cast<T *>(smem_raw);
+
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gid < n;
+    const int64_t r = active ? gid : n - 1;  // idle lanes shadow the last rollout, stores masked
+
+    T s[10], ax, ay;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = state0[(int64_t)i * n + r];
+    ax = state0[10 * n + r];
+    ay = state0[11 * n + r];
+
+    int pid = 0;
+    if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);  // ids outside [0, P) are clamped, never read out of bounds
+
+    T sd[10];
+    Outputs18<T> o18;
+    constexpr bool REAR = (K == 12);
+
+    for (int t0 = 0; t0 < H; t0 += chunk) {
+        const int tc_n = min(chunk, H - t0);
+        if (LAYOUT == 1) {
+            __syncthreads();  // previous chunk fully consumed
+            const int total = tc_n * K * Pn;
+            for (int idx = threadIdx.x; idx < total; idx += kBlock) {
+                const int p = idx % Pn;
+                const int kk = (idx / Pn) % K;
+                const int tc = idx / (Pn * K);
+                tab[idx] = ctrl[((int64_t)p * H + (t0 + tc)) * K + kk];
+            }
+            __syncthreads();
+        }
+        for (int tc = 0; tc < tc_n; ++tc) {
+            const int t = t0 + tc;
+            Ctrl<T, K> c;
+            if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
+            else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
+            else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
+
+            rk4_step<T, REAR, DIAG>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
+
+            if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) row[(int64_t)i * n] = s[i];
+                row[10 * n] = ax;
+                row[11 * n] = ay;
+            }
+        }
+    }
+
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) terminal[(int64_t)i * n + r] = s[i];
+        terminal[10 * n + r] = ax;
+        terminal[11 * n + r] = ay;
+        if (DIAG) {
+            if (state_dot_out != nullptr && H > 0) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) state_dot_out[(int64_t)i * n + r] = sd[i];
+            }
+            if (outputs_out != nullptr && H > 0) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) outputs_out[(int64_t)i * n + r] = o18.v[i];
+            }
+        }
+    }
+}
+
+// One derivative evaluation per lane: vehicle_model.py:220-425 with its full
+// return list (:425).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, const T *__restrict__ ctrl12,
+                    const T *__restrict__ acc_prev, T *__restrict__ state_dot, T *__restrict__ aux,
+                    T *__restrict__ outputs, T *__restrict__ acc)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    T s[10], k[10], axc, ayc;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = state[(int64_t)i * n + r];
+    Ctrl<T, 12> c;
+    c.set(P, ctrl12 + r, n);
+    StepInv<T> inv;
+    make_step_inv<T, true>(P, c.delta, c.tq, c.mu, acc_prev[r], acc_prev[n + r], inv);
+    Outputs18<T> o;
+    planar_deriv<T, true, true>(P, inv, s, k, axc, ayc, &o);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) state_dot[(int64_t)i * n + r] = k[i];
+    acc[r] = axc;
+    acc[n + r] = ayc;
+    if (aux != nullptr) {
+        T sy, cy;
+        Math<T>::sincos(s[7], &sy, &cy);
+        aux[r] = s[0] * cy - s[1] * sy;          // vx, :410
+        aux[n + r] = s[1] * sy + s[0] * cy;      // vy, :411 (the reference's own sin/cos mix-up)
+        aux[2 * n + r] = axc * cy - ayc * sy;    // ax, :415
+        aux[3 * n + r] = axc * sy + ayc * cy;    // ay, :416
+    }
+    if (outputs != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) outputs[(int64_t)i * n + r] = o.v[i];
+    }
+}
+
+// Config-5 MPC selection.  Block = one ego; lanes stride over the C shared
+// candidates; cost and (min, argmin) never leave the chip until the final pair.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego,
+                  const T *__restrict__ cand, const T *__restrict__ goal, T h, T w_delta,
+                  T *__restrict__ best_cost, int *__restrict__ best_idx, T *__restrict__ cost_all)
+{
+    __shared__ T s_cost[16];
+    __shared__ int s_idx[16];
+    const int e = blockIdx.x;
+    const T inf = T(INFINITY);
+    constexpr int kNone = 0x7fffffff;
+
+    T s0[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s0[i] = ego[(int64_t)i * E + e];
+    const T ax0 = ego[(int64_t)10 * E + e], ay0 = ego[(int64_t)11 * E + e];
+    const T gx = goal[e], gy = goal[(int64_t)E + e];
+
+    T bc = inf;
+    int bi = kNone;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        T s[10], ax = ax0, ay = ay0, dsum = T(0);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s[i] = s0[i];
+        for (int t = 0; t < H; ++t) {
+            Ctrl<T, 2> cc;
+            cc.set(P, cand + ((int64_t)t * 2) * C + c, C);
+            rk4_step<T, false, false>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h, nullptr, nullptr);
+            dsum += cc.delta[0] * cc.delta[0];
+        }
+        const T dx = s[8] - gx, dy = s[9] - gy;
+        const T cost = Math<T>::sqrt(dx * dx + dy * dy) + w_delta * dsum;
+        if (cost_all != nullptr) cost_all[(int64_t)e * C + c] = cost;
+        if (cost < bc) { bc = cost; bi = c; }  // strict '<': lowest index wins ties; NaN/inf never win
+    }
+    // wave-level (cost, idx) lexicographic min
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T oc = __shfl_xor(bc, off);
+        const int oi = __shfl_xor(bi, off);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { s_cost[wave] = bc; s_idx[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) {
+            const T oc = s_cost[w];
+            const int oi = s_idx[w];
+            if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+        }
+        best_cost[e] = bc;
+        best_idx[e] = (bi == kNone) ? -1 : bi;
+    }
+}
+
+// ---------------------------------------------------------------- launchers ---------
+
+template <typename T>
+DevParams<T> make_dev_params(const VdynParams &p, const double *mu4)
+{
+    DevParams<T> d;
+    d.inv_m = (T)(1.0 / p.m);
+    d.inv_Izz = (T)(1.0 / p.Izz);
+    d.inv_Jw = (T)(1.0 / p.Jw);
+    d.a = (T)p.a;
+    d.b = (T)p.b;
+    d.half_T = (T)(p.T / 2);
+    d.rw = (T)p.rw;
+    const double L = p.a + p.b, W = p.wL + p.wR;
+    d.Fz0F = (T)(p.b / L * p.m * p.g / 2);   // vehicle_model.py:245-246
+    d.Fz0R = (T)(p.a / L * p.m * p.g / 2);   // :247-248
+    d.DfzxL = (T)(p.m * p.hg * p.wR / (L * W));  // :250
+    d.DfzxR = (T)(p.m * p.hg * p.wL / (L * W));  // :251
+    d.DfzyF = (T)(p.m * p.hg * p.b / (L * W));   // :252
+    d.DfzyR = (T)(p.m * p.hg * p.a / (L * W));   // :253
+    for (int i = 0; i < 4; ++i) {
+        d.B[i] = (T)p.B[i];
+        d.C[i] = (T)p.C[i];
+        d.mu[i] = mu4 ? (T)mu4[i] : (T)1;
+    }
+    return d;
+}
+
+template <typename T, int K, int LAYOUT, bool DIAG>
+static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
+{
+    const DevParams<T> P = make_dev_params<T>(p, a.mu4);
+    const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    int chunk = a.H > 0 ? a.H : 1;
+    size_t lds = 0;
+    if (LAYOUT == 1) {
+        const size_t per_step = (size_t)a.P * K * sizeof(T);
+        chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
+        lds = (size_t)chunk * per_step;
+    }
+    hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+                       a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                       a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
+{
+    if (a.n <= 0) return hipSuccess;
+    int layout = a.layout;
+    if (layout == VDYN_CTRL_SHARED && (size_t)a.P * a.k * sizeof(T) > (size_t)kLdsBudget) layout = 2;
+    const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
+#define VDYN_DISPATCH(KK, LL)                                                          \
+    if (a.k == KK && layout == LL)                                                     \
+        return diag ? launch_rollout_impl<T, KK, LL, true>(p, a, st)                   \
+                    : launch_rollout_impl<T, KK, LL, false>(p, a, st);
+    VDYN_DISPATCH(2, 0)
+    VDYN_DISPATCH(2, 1)
+    VDYN_DISPATCH(2, 2)
+    VDYN_DISPATCH(12, 0)
+    VDYN_DISPATCH(12, 1)
+    VDYN_DISPATCH(12, 2)
+#undef VDYN_DISPATCH
+    return hipErrorInvalidValue;
+}
+
+template <typename T>
+hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, const T *ctrl12,
+                               const T *acc_prev, T *state_dot, T *aux, T *outputs, T *acc,
+                               hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const DevParams<T> P = make_dev_params<T>(p, nullptr);
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((planar_model_kernel<T>), dim3(grid), dim3(kBlock), 0, st, P, n, state, ctrl12,
+                       acc_prev, state_dot, aux, outputs, acc);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *ego, const T *cand,
+                             const T *goal, double dt, double w_delta, T *best_cost, int *best_idx,
+                             T *cost_all, hipStream_t st)
+{
+    if (E <= 0) return hipSuccess;
+    const DevParams<T> P = make_dev_params<T>(p, nullptr);
+    int block = ((C + 63) / 64) * 64;
+    block = std::max(64, std::min(block, 1024));
+    hipLaunchKernelGGL((mpc_argmin_kernel<T>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E, C,
+                       H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+    return hipGetLastError();
+}
+
+#define VDYN_INSTANTIATE(T)                                                                          \
+    template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
+    template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
+                                               const T *, T *, T *, T *, T *, hipStream_t);          \
+    template hipError_t launch_mpc_argmin<T>(const VdynParams &, int, int, int, const T *, const T *, \
+                                             const T *, double, double, T *, int *, T *, hipStream_t);
+VDYN_INSTANTIATE(float)
+VDYN_INSTANTIATE(double)
+
+}  // namespace vdyn

@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference's vehicle-model interface, executed on MI355X.
+
+``VehicleModel`` keeps the constructor, method names, argument meaning and
+return lists of /root/reference/libs/vehicle_model/vehicle_model.py
+(``VehicleModel.__init__`` :69-95, ``planar_model`` :220-425,
+``planar_model_RK4`` :427-445) so that drive.py:109 / drive.py:141-143 can use
+it unchanged, and adds the batched entry points BASELINE.json's north_star
+names: ``step``, ``rollout`` and ``mpc_argmin``.
+
+Every method runs the hand-written HIP kernels behind ``include/vdyn.h``.
+There is no NumPy or CPU implementation of the model in this package.
+
+Batched arrays are struct-of-arrays, ``[rows][N]`` (see include/vdyn.h):
+``state12`` rows ``U,V,wz,wFL,wFR,wRL,wRR,yaw,x,y,ax_prev,ay_prev``.
+NumPy inputs go through the ``_host`` ABI (staged copies, synchronous);
+torch CUDA tensors go through the ``_dev`` ABI zero-copy on torch's current
+stream (asynchronous, like any torch op).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VdynError, VdynParams  # noqa: F401  (re-exported)
+
+_WHEELS = ("FL", "FR", "RL", "RR")
+
+
+class VehicleParameters:
+    """Same constructor arguments and attribute names as the reference's
+    ``VehicleParameters`` (vehicle_model.py:17-61), so objects of either class
+    can be passed as ``p``."""
+
+    def __init__(self, mf=987.89, mr=869.93, mus=50, L=2.906, ab_ratio=0.85, T=1.536,
+                 hg=0.55419, Jw=1, kf=26290, kr=25830, Efront=0.0376, Erear=0,
+                 LeverArm=0.13256, BFL=20.6357, CFL=1.5047, DFL=1.1233):
+        self.rr = 0.329
+        self.mus, self.mf, self.mr = mus, mf, mr
+        self.m = mf + mr
+        self.L, self.ab_ratio = L, ab_ratio
+        self.b = L / (1 + ab_ratio)
+        self.a = L - self.b
+        self.Izz = 0.5 * self.m * self.a * self.b
+        self.Jw, self.hg, self.T = Jw, hg, T
+        self.kf, self.kr = kf, kr
+        self.rw = self.rr - (mf / 2 + mus) / kf
+        for w in _WHEELS:  # one tire model on all four corners (:41-54)
+            setattr(self, "B" + w, BFL)
+            setattr(self, "C" + w, CFL)
+            setattr(self, "D" + w, DFL)
+        self.Efront, self.Erear = Efront, Erear
+        self.E = [Efront, Efront, Erear, Erear]
+        self.LeverArm = LeverArm
+        self.wL = self.wR = T / 2
+
+
+def params_to_c(p) -> VdynParams:
+    """Any object with the reference's VehicleParameters attributes -> VdynParams."""
+    c = VdynParams()
+    for n in ("m", "a", "b", "Izz", "Jw", "hg", "T", "wL", "wR", "rw"):
+        setattr(c, n, float(getattr(p, n)))
+    c.g = 9.81  # vehicle_model.py:230
+    for i, w in enumerate(_WHEELS):
+        c.B[i] = float(getattr(p, "B" + w))
+        c.C[i] = float(getattr(p, "C" + w))
+    return c
+
+
+def _is_torch_cuda(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64"
+    if dtype == np.float32:
+        return "f32"
+    raise ValueError(f"unsupported dtype {dtype}: float32 or float64 only")
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())
+
+
+class _Backend:
+    """Uniform view over NumPy (host ABI) and torch-CUDA (device ABI) buffers."""
+
+    def __init__(self, like, dtype=None):
+        self.torch = _is_torch_cuda(like)
+        if self.torch:
+            import torch
+            self._t = torch
+            self.device = like.device
+            self.np_dtype = np.dtype({torch.float32: np.float32, torch.float64: np.float64}[like.dtype]) \
+                if like.dtype in (torch.float32, torch.float64) else None
+            if self.np_dtype is None:
+                raise ValueError("unsupported tensor dtype: float32 or float64 only")
+            self.t_dtype = like.dtype
+        else:
+            self.np_dtype = np.dtype(dtype or np.asarray(like).dtype)
+            if self.np_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+                self.np_dtype = np.dtype(np.float64)
+        self.suffix = _suffix(self.np_dtype)
+        self.kind = "dev" if self.torch else "host"
+
+    def inp(self, x, shape=None, int32=False):
+        """Contiguous input buffer of the call's dtype (never modified)."""
+        if x is None:
+            return None
+        if self.torch:
+            want = self._t.int32 if int32 else self.t_dtype
+            if not _is_torch_cuda(x):
+                x = self._t.as_tensor(np.asarray(x), device=self.device)
+            if x.device != self.device:
+                raise ValueError("all tensors of one call must live on the same device")
+            x = x.to(want).contiguous()
+        else:
+            x = np.ascontiguousarray(x, dtype=np.int32 if int32 else self.np_dtype)
+        if shape is not None and tuple(x.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(x.shape)}")
+        return x
+
+    def out(self, *shape, int32=False):
+        if self.torch:
+            return self._t.empty(shape, dtype=self._t.int32 if int32 else self.t_dtype, device=self.device)
+        return np.empty(shape, dtype=np.int32 if int32 else self.np_dtype)
+
+    def stream_args(self):
+        if not self.torch:
+            return ()
+        return (C.c_void_p(self._t.cuda.current_stream(self.device).cuda_stream),)
+
+    def device_index(self, default):
+        if self.torch:
+            return self.device.index if self.device.index is not None else self._t.cuda.current_device()
+        return default
+
+
+class VehicleModel:
+    """Drop-in for the reference ``VehicleModel`` on the RK4 / Pacejka path.
+
+    ``VehicleModel(wheelbase, max_steer, dt)`` as at drive.py:109; only ``dt``
+    matters to this path (vehicle_model.py:93,:428).  ``device`` selects the
+    GPU used for NumPy inputs (torch tensors bring their own device)."""
+
+    def __init__(self, wheelbase=1.0, max_steer=0.7, dt=0.05, device=0, params=None):
+        self.dt = dt
+        self.wheelbase = wheelbase
+        self.max_steer = max_steer
+        self.device = int(device)
+        self.params = params if params is not None else VehicleParameters()
+        self._handles = {}
+        _lib.load()  # fail now, loudly, if the HIP library is not built
+
+    # ------------------------------------------------------------------ plumbing
+    def _handle(self, device, p=None):
+        cp = params_to_c(p if p is not None else self.params)
+        h = self._handles.get(device)
+        if h is None:
+            h = self._handles[device] = _lib.Handle(cp, device)
+        else:
+            h.set_params(cp)
+        return h
+
+    @staticmethod
+    def _mu4(mu_max):
+        if mu_max is None:
+            return None, None
+        a = np.ascontiguousarray(mu_max, dtype=np.float64)
+        if a.shape != (4,):
+            raise ValueError("mu_max must have 4 entries (FL, FR, RL, RR)")
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    # ------------------------------------------------- reference-signature drop-ins
+    def planar_model(self, state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
+        """vehicle_model.py:220-425: returns
+        ``[state_dot(10), vx, vy, ax, ay, outputs(18), axc, ayc]`` (:425)."""
+        st, c12, acc = self._pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev)
+        sd, aux, out, ac = (np.empty(k) for k in (10, 4, 18, 2))
+        self._handle(self.device, p).call("vdyn_planar_model_f64_host", 1, _vp(st), _vp(c12), _vp(acc),
+                                          _vp(sd), _vp(aux), _vp(out), _vp(ac))
+        return [sd, aux[0], aux[1], aux[2], aux[3], out, ac[0], ac[1]]
+
+    def planar_model_RK4(self, state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
+        """vehicle_model.py:427-445: returns
+        ``[state_update(10), x, y, yaw, U, state_dot(10), outputs(18), axc, ayc]`` (:445)."""
+        st, c12, acc = self._pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev)
+        s12 = np.concatenate([st, acc])
+        so, sd, out = np.empty(12), np.empty(10), np.empty(18)
+        self._handle(self.device, p).call("vdyn_step_f64_host", 1, _vp(s12), _vp(c12), 12,
+                                          float(self.dt), None, _vp(so), _vp(sd), _vp(out))
+        su = so[:10].copy()
+        return [su, su[8], su[9], su[7], su[0], sd, out, so[10], so[11]]
+
+    @staticmethod
+    def _pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
+        st = np.ascontiguousarray(state, dtype=np.float64)         # lists allowed (quirk Q9)
+        tq = np.asarray(tire_torques, dtype=np.float64)
+        mu = np.asarray(mu_max, dtype=np.float64)
+        de = np.asarray(delta, dtype=np.float64)
+        if st.shape != (10,) or tq.shape != (4,) or mu.shape != (4,) or de.shape != (4,):
+            raise ValueError("planar model expects state[10], tire_torques[4], mu_max[4], delta[4]")
+        # vehicle_model.py:232-235 (quirk Q1): the reference stores mu_max into p.D**
+        for w, v in zip(_WHEELS, mu_max):
+            try:
+                setattr(p, "D" + w, v)
+            except AttributeError:
+                pass
+        return st, np.concatenate([de, tq, mu]), np.array([ax_prev, ay_prev], dtype=np.float64)
+
+    # ----------------------------------------------------------------- batched API
+    def step(self, states, controls, dt=None, mu_max=None, p=None, return_diag=False):
+        """One RK4 step for N vehicles: ``states [12][N]``, ``controls [k][N]``
+        (k = 2: delta_front, torque_all; k = 12: delta4, torque4, mu4).
+        Returns ``states' [12][N]`` (and ``state_dot [10][N]``, ``outputs [18][N]``
+        when ``return_diag``)."""
+        be = _Backend(states)
+        st = be.inp(states)
+        if st.ndim != 2 or st.shape[0] != 12:
+            raise ValueError("states must be [12][N]")
+        n = st.shape[1]
+        ct = be.inp(controls)
+        if ct.ndim != 2 or ct.shape[0] not in (2, 12) or ct.shape[1] != n:
+            raise ValueError("controls must be [2][N] or [12][N]")
+        keep, mu4 = self._mu4(mu_max)
+        so = be.out(12, n)
+        sd = be.out(10, n) if return_diag else None
+        ou = be.out(18, n) if return_diag else None
+        self._handle(be.device_index(self.device), p).call(
+            f"vdyn_step_{be.suffix}_{be.kind}", n, _vp(st), _vp(ct), int(ct.shape[0]),
+            float(self.dt if dt is None else dt), mu4, _vp(so), _vp(sd), _vp(ou), *be.stream_args())
+        del keep
+        return (so, sd, ou) if return_diag else so
+
+    def planar_model_batch(self, state, ctrl12, acc_prev, p=None, return_aux=True):
+        """N derivative evaluations (vehicle_model.py:220-425): ``state [10][N]``,
+        ``ctrl12 [12][N]``, ``acc_prev [2][N]`` -> ``state_dot [10][N]``,
+        ``aux [4][N]`` (vx, vy, ax, ay), ``outputs [18][N]``, ``acc [2][N]``."""
+        be = _Backend(state)
+        st = be.inp(state)
+        if st.ndim != 2 or st.shape[0] != 10:
+            raise ValueError("state must be [10][N]")
+        n = st.shape[1]
+        c12 = be.inp(ctrl12, shape=(12, n))
+        ap = be.inp(acc_prev, shape=(2, n))
+        sd, ac = be.out(10, n), be.out(2, n)
+        aux = be.out(4, n) if return_aux else None
+        ou = be.out(18, n) if return_aux else None
+        self._handle(be.device_index(self.device), p).call(
+            f"vdyn_planar_model_{be.suffix}_{be.kind}", n, _vp(st), _vp(c12), _vp(ap), _vp(sd), _vp(aux),
+            _vp(ou), _vp(ac), *be.stream_args())
+        return sd, aux, ou, ac
+
+    def rollout(self, states0, controls, dt=None, path_id=None, mu_max=None, traj_stride=0, p=None):
+        """H zero-order-hold RK4 steps in one launch.
+
+        ``states0 [12][N]``; ``controls [H][k][N]`` (per rollout) or, with
+        ``path_id [N]``, a shared table ``[P][H][k]`` staged in LDS.
+        Returns ``terminal [12][N]`` (and ``traj [H//traj_stride][12][N]`` when
+        ``traj_stride > 0``)."""
+        be = _Backend(states0)
+        s0 = be.inp(states0)
+        if s0.ndim != 2 or s0.shape[0] != 12:
+            raise ValueError("states0 must be [12][N]")
+        n = s0.shape[1]
+        ct = be.inp(controls)
+        if ct.ndim != 3:
+            raise ValueError("controls must be [H][k][N] or [P][H][k]")
+        if path_id is None:
+            H, k, nn = ct.shape
+            if nn != n:
+                raise ValueError("controls must be [H][k][N] with N matching states0")
+            layout, P, pid = _lib.VDYN_CTRL_PER_ROLLOUT, 0, None
+        else:
+            P, H, k = ct.shape
+            pid = be.inp(path_id, shape=(n,), int32=True)
+            # host arrays are range-checked here; device tensors are not (that would
+            # cost a device sync per call) -- the kernel clamps ids into [0, P)
+            if not be.torch and n and (int(pid.min()) < 0 or int(pid.max()) >= P):
+                raise ValueError("path_id out of range")
+            layout = _lib.VDYN_CTRL_SHARED
+        if k not in (2, 12):
+            raise ValueError("k must be 2 or 12")
+        if traj_stride < 0:
+            raise ValueError("traj_stride must be >= 0")
+        keep, mu4 = self._mu4(mu_max)
+        term = be.out(12, n)
+        traj = be.out(H // traj_stride, 12, n) if traj_stride > 0 else None
+        self._handle(be.device_index(self.device), p).call(
+            f"vdyn_rollout_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(ct), int(k), layout,
+            _vp(pid), int(P), float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj),
+            int(traj_stride), *be.stream_args())
+        del keep
+        return (term, traj) if traj_stride > 0 else term
+
+    def mpc_argmin(self, ego, cand, goal, dt=None, w_delta=1e-3, return_costs=False, p=None):
+        """BASELINE config 5: ``ego [12][E]``, shared candidates ``cand [H][2][C]``,
+        ``goal [2][E]`` -> ``(best_cost [E], best_idx [E])`` (+ ``cost [E][C]``)."""
+        be = _Backend(ego)
+        eg = be.inp(ego)
+        if eg.ndim != 2 or eg.shape[0] != 12:
+            raise ValueError("ego must be [12][E]")
+        E = eg.shape[1]
+        cd = be.inp(cand)
+        if cd.ndim != 3 or cd.shape[1] != 2 or cd.shape[2] < 1:
+            raise ValueError("cand must be [H][2][C] with C >= 1")
+        H, _, Cn = cd.shape
+        gl = be.inp(goal, shape=(2, E))
+        bc, bi = be.out(E), be.out(E, int32=True)
+        costs = be.out(E, Cn) if return_costs else None
+        self._handle(be.device_index(self.device), p).call(
+            f"vdyn_mpc_argmin_{be.suffix}_{be.kind}", int(E), int(Cn), int(H), _vp(eg), _vp(cd), _vp(gl),
+            float(self.dt if dt is None else dt), float(w_delta), _vp(bc), _vp(bi), _vp(costs),
+            *be.stream_args())
+        return (bc, bi, costs) if return_costs else (bc, bi)
+
+    def synchronize(self, device=None):
+        """Wait for the default stream of `device` (NumPy calls are already synchronous)."""
+        d = self.device if device is None else device
+        self._handle(d).call("vdyn_stream_synchronize", None)

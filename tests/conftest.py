@@ -42,3 +42,33 @@ def rel_err(a, b, floor=1e-9):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def parity(got, want, tol, what=""):
+    """The parity bar of BASELINE.json's north_star: relative error `tol`
+    (1e-6 fp64, 1e-3 fp32) per state row, |got - want| <= tol * max(|want|, row scale),
+    where the row scale is max|want| over the row (so rows that cross zero are
+    judged against their own magnitude).  `got`, `want`: [rows][N] (or [..., rows, N])."""
+    g = np.asarray(got, dtype=np.float64)
+    w = np.asarray(want, dtype=np.float64)
+    assert g.shape == w.shape, (g.shape, w.shape)
+    assert np.isfinite(w).all(), "reference values must be finite"
+    assert np.isfinite(g).all(), f"{what}: non-finite result"
+    if g.size == 0:
+        return 0.0
+    scale = np.maximum(np.abs(w).max(axis=-1, keepdims=True), 1e-30)
+    err = np.abs(g - w) / np.maximum(np.abs(w), scale)
+    worst = float(err.max())
+    assert worst <= tol, f"{what}: relative error {worst:.3e} > {tol:g}"
+    return worst
+
+
+@pytest.fixture(scope="session")
+def gpu_vm(pkg):
+    """VehicleModel factory on cuda:0; skips nothing: -m gpu tests REQUIRE the HIP path."""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+
+    def make(dt, **kw):
+        return pkg.VehicleModel(2.906, np.deg2rad(30), dt, device=0, **kw)
+    return make

@@ -1,0 +1,343 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (include/vdyn.h via the
+ctypes shim), against (1) the committed golden vectors of the reference,
+(2) the oracle on the same seeded inputs, (3) size-independent properties at
+BASELINE.json's full sizes.  Tolerances are north_star's: 1e-6 relative in
+fp64, 1e-3 in fp32 (conftest.parity); the tighter GUARD_* bounds are regression
+guards around what the kernels actually achieve."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, parity
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL, F32_TOL = 1e-6, 1e-3
+GUARD_F64 = 1e-9
+
+
+def ctrl12(delta, torque, mu):
+    return np.concatenate([np.asarray(delta, float), np.asarray(torque, float), np.asarray(mu, float)])
+
+
+# ------------------------------------------------------------------ golden vectors
+def test_g1_planar_model_RK4_dropin(gpu_vm, pkg):
+    """Reference signature / return list (vehicle_model.py:427-445), 17 known answers."""
+    g = load_golden("g1_step_kat.npz")
+    vm = gpu_vm(float(g["dt"]))
+    for i in range(len(g["state"])):
+        p = pkg.VehicleParameters()
+        o = vm.planar_model_RK4(list(g["state"][i]), list(g["torque"][i]), list(g["mu"][i]),
+                                list(g["delta"][i]), p, 0, 0)
+        assert len(o) == 9 and o[0].shape == (10,) and o[5].shape == (10,) and o[6].shape == (18,)
+        parity(o[0][None, :].T, g["state_update"][i][None, :].T, GUARD_F64, "state_update")
+        assert (o[1], o[2], o[3], o[4]) == (o[0][8], o[0][9], o[0][7], o[0][0])
+        sc = np.abs(g["state_dot"][i]).max()
+        assert np.abs(o[5] - g["state_dot"][i]).max() <= GUARD_F64 * sc
+        sc = np.abs(g["outputs"][i]).max()
+        assert np.abs(o[6] - g["outputs"][i]).max() <= GUARD_F64 * sc
+        assert abs(o[7] - g["acc"][i][0]) <= GUARD_F64 * max(1, abs(g["acc"][i][0]))
+        assert abs(o[8] - g["acc"][i][1]) <= GUARD_F64 * max(1, abs(g["acc"][i][1]))
+        assert p.DFL == 1.0 and p.DRR == 1.0  # quirk Q1 side effect reproduced on `p`
+
+
+def test_g2_planar_model_dropin_and_batch(gpu_vm, pkg):
+    g = load_golden("g2_deriv.npz")
+    vm = gpu_vm(1e-4)
+    n = len(g["state"])
+    for i in range(0, n, 7):
+        o = vm.planar_model(g["state"][i], g["torque"][i], g["mu"][i], g["delta"][i],
+                            pkg.VehicleParameters(), *g["ax_ay_prev"][i])
+        assert len(o) == 8
+        assert np.abs(o[0] - g["state_dot"][i]).max() <= GUARD_F64 * np.abs(g["state_dot"][i]).max()
+        assert np.abs(np.array(o[1:5]) - g["aux"][i]).max() <= GUARD_F64 * np.abs(g["aux"][i]).max()
+        assert np.abs(o[5] - g["outputs"][i]).max() <= GUARD_F64 * np.abs(g["outputs"][i]).max()
+        assert np.abs(np.array(o[6:8]) - g["acc"][i]).max() <= GUARD_F64 * np.abs(g["acc"][i]).max()
+    c12 = np.concatenate([g["delta"], g["torque"], g["mu"]], axis=1).T
+    for dtype, tol in ((np.float64, GUARD_F64), (np.float32, 2e-4)):
+        sd, aux, out, acc = vm.planar_model_batch(g["state"].T.astype(dtype), c12.astype(dtype),
+                                                  g["ax_ay_prev"].T.astype(dtype))
+        assert sd.dtype == dtype
+        for got, want in ((sd, g["state_dot"].T), (aux, g["aux"].T), (out, g["outputs"].T),
+                          (acc, g["acc"].T)):
+            sc = np.abs(want).max(axis=1, keepdims=True)
+            assert (np.abs(got - want) <= tol * np.maximum(sc, 1e-12)).all()
+
+
+@pytest.mark.parametrize("tag,dt", [("dt1e-4", 1e-4), ("dt1e-3", 1e-3)])
+def test_g3_rollouts_cfg2(gpu_vm, tag, dt):
+    g = load_golden("g3_rollout_cfg2.npz")
+    vm = gpu_vm(dt)
+    term, traj = vm.rollout(g["state0"], g["ctrl"], traj_stride=20)
+    assert parity(term, g["terminal_" + tag], F64_TOL, "terminal") <= GUARD_F64
+    assert parity(traj, g["every20_" + tag], F64_TOL, "traj") <= GUARD_F64
+    t32 = vm.rollout(g["state0"].astype(np.float32), g["ctrl"].astype(np.float32))
+    e = parity(t32, g["terminal_" + tag], F32_TOL, "fp32 terminal")
+    assert np.abs(t32 - g["terminal_" + tag]).max() <= 1e-3      # the metric's max-abs form
+    print(f"\n  G3 {tag}: fp32 row-relative err {e:.2e}, max-abs "
+          f"{np.abs(t32 - g['terminal_' + tag]).max():.2e}")
+
+
+@pytest.mark.parametrize("tag", ["world", "waypoints"])
+def test_g4_closed_loop_replay(gpu_vm, pkg, tag):
+    """Every RK4 call of 3 frames of the reference's Car.drive (drive.py:141-143),
+    replayed through the drop-in with the logged inputs; then the same 300 steps as
+    one k = 12 rollout launch."""
+    g = load_golden(f"g4_closed_loop_{tag}.npz")
+    dt = float(g["dt"])
+    vm = gpu_vm(dt)
+    p = pkg.VehicleParameters()
+    n = len(g["state"])
+    for i in range(n):
+        o = vm.planar_model_RK4(g["state"][i], g["torque"][i], g["mu"][i], g["delta"][i], p,
+                                *g["ax_ay_prev"][i])
+        assert np.abs(o[0] - g["state_update"][i]).max() <= GUARD_F64 * np.abs(g["state_update"][i]).max()
+        assert np.abs(o[5] - g["state_dot"][i]).max() <= GUARD_F64 * max(np.abs(g["state_dot"][i]).max(), 1)
+        assert np.abs(o[6] - g["outputs"][i]).max() <= GUARD_F64 * np.abs(g["outputs"][i]).max()
+        assert abs(o[7] - g["acc"][i][0]) <= 1e-8 and abs(o[8] - g["acc"][i][1]) <= 1e-8
+    ctrl = np.concatenate([g["delta"], g["torque"], g["mu"]], axis=1)[:, :, None]
+    s0 = np.concatenate([g["state"][0], g["ax_ay_prev"][0]])[:, None]
+    term, traj = vm.rollout(s0, ctrl, traj_stride=1)
+    want = np.concatenate([g["state_update"], g["acc"]], axis=1)      # [300][12]
+    assert np.abs(traj[:, :, 0] - want).max() <= 1e-8 * np.abs(want).max()
+    assert np.array_equal(traj[-1], term)
+
+
+def test_g5_quirks(gpu_vm):
+    g = load_golden("g5_quirks.npz")
+    H, dt = int(g["H"]), float(g["dt"])
+    vm = gpu_vm(dt)
+    n = len(g["names"])
+    c = np.concatenate([g["delta"], g["torque"], g["mu"]], axis=1).T          # [12][n]
+    s0 = g["state0"].T                                                         # [12][n]
+    so, sd, out = vm.step(s0, c, return_diag=True)
+    first = np.concatenate([so, sd, out]).T
+    for i, name in enumerate(g["names"]):
+        f = g["first_step"][i]
+        for lo, hi in ((0, 12), (12, 22), (22, 40)):
+            sc = max(np.abs(f[lo:hi]).max(), 1e-300)
+            assert np.abs(first[i, lo:hi] - f[lo:hi]).max() <= GUARD_F64 * sc, (name, lo)
+    term = vm.rollout(s0, np.broadcast_to(c[None], (H, 12, n)).copy())
+    assert parity(term, g["terminal"].T, F64_TOL, "quirks terminal") <= 1e-8
+
+
+def test_g8_rollouts_cfg3_shared_controls(gpu_vm):
+    g = load_golden("g8_rollout_cfg3.npz")
+    vm = gpu_vm(float(g["dt"]))
+    t64, traj = vm.rollout(g["state0"].astype(np.float64), g["table"].astype(np.float64),
+                           path_id=g["path_id"], traj_stride=50)
+    assert parity(t64, g["terminal"], F64_TOL) <= GUARD_F64
+    assert parity(traj, g["every50"], F64_TOL) <= GUARD_F64
+    t32 = vm.rollout(g["state0"], g["table"], path_id=g["path_id"])
+    assert t32.dtype == np.float32
+    e = parity(t32, g["terminal"], F32_TOL, "fp32 vs reference fp64")
+    assert np.abs(t32 - g["terminal"]).max() <= 1e-3
+    print(f"\n  G8: fp32 row-relative err {e:.2e}, max-abs {np.abs(t32 - g['terminal']).max():.2e}")
+
+
+def test_g7_mpc(gpu_vm):
+    g = load_golden("g7_mpc.npz")
+    vm = gpu_vm(float(g["dt"]))
+    ego, cand, goal = (g[k].astype(np.float64) for k in ("ego", "cand", "goal"))
+    bc, bi, cost = vm.mpc_argmin(ego, cand, goal, w_delta=float(g["w_delta"]), return_costs=True)
+    assert np.abs(cost - g["cost"]).max() <= 1e-9 * np.abs(g["cost"]).max()
+    assert np.array_equal(bi, g["best_idx"])
+    assert np.abs(bc - g["best_cost"]).max() <= 1e-9
+    bc32, bi32, c32 = vm.mpc_argmin(g["ego"], g["cand"], g["goal"], w_delta=float(g["w_delta"]),
+                                    return_costs=True)
+    assert np.abs(c32 - g["cost"]).max() <= 1e-3
+    # the fp32 winner's true cost is within fp32 noise of the true minimum
+    E = len(bi32)
+    assert (g["cost"][np.arange(E), bi32] <= g["best_cost"] + 1e-4).all()
+    assert np.array_equal(bc32, c32[np.arange(E), bi32])
+
+
+# --------------------------------------------------- oracle, BASELINE sizes, properties
+def test_config2_full_fp64_vs_oracle(gpu_vm, oracle, workloads):
+    """configs[1]: 4096 rollouts x 200 steps, fp64, 1e-6 relative."""
+    s0, ctrl = workloads.config2(64, 200)
+    p = oracle.default_params()
+    for dt in (1e-3, 1e-4):
+        term = gpu_vm(dt).rollout(s0, ctrl)
+        want = oracle.rollout(p, s0, ctrl, dt, nthreads=oracle.max_threads())
+        e = parity(term, want, F64_TOL, f"config2 dt={dt}")
+        assert e <= GUARD_F64
+        print(f"\n  config2 dt={dt}: fp64 rel err {e:.2e}")
+
+
+def test_config3_full_fp32_vs_oracle_and_properties(gpu_vm, oracle, workloads):
+    """configs[2]: 65536 rollouts x 200 steps, fp32 vs the fp64 oracle on ALL rollouts;
+    LDS-shared controls == per-rollout controls bit for bit; run-to-run determinism;
+    a split horizon (80 + 120 steps) == one launch bit for bit."""
+    import torch
+    dt = 1e-3
+    s0, tab, pid = workloads.config3(65536, 200)
+    vm = gpu_vm(dt)
+    dev = torch.device("cuda:0")
+    s0d, tabd, pidd = (torch.from_numpy(a).to(dev) for a in (s0, tab, pid))
+    term = vm.rollout(s0d, tabd, path_id=pidd)
+    torch.cuda.synchronize()
+    term_h = term.cpu().numpy()
+    want = oracle.rollout(oracle.default_params(), s0.astype(np.float64), tab.astype(np.float64), dt,
+                          path_id=pid, nthreads=oracle.max_threads())
+    e = parity(term_h, want, F32_TOL, "config3 fp32")
+    mabs = np.abs(term_h - want).max()
+    assert mabs <= 1e-3
+    print(f"\n  config3: fp32 row-relative err {e:.2e}, max-abs {mabs:.2e}")
+
+    ctrl = torch.from_numpy(workloads.expand_shared_controls(tab, pid)).to(dev)
+    term_pr = vm.rollout(s0d, ctrl)
+    assert torch.equal(term, term_pr)
+    assert torch.equal(term, vm.rollout(s0d, tabd, path_id=pidd))
+    mid = vm.rollout(s0d, ctrl[:80].contiguous())
+    assert torch.equal(term, vm.rollout(mid, ctrl[80:].contiguous()))
+    # host ABI == device ABI
+    assert np.array_equal(vm.rollout(s0[:, :4099], tab, path_id=pid[:4099]), term_h[:, :4099])
+
+
+def test_step_chain_equals_rollout_and_traj(gpu_vm, workloads):
+    s0, ctrl = workloads.config2(16, 12)
+    vm = gpu_vm(1e-3)
+    term, traj = vm.rollout(s0, ctrl, traj_stride=3)
+    s = s0
+    for t in range(12):
+        s = vm.step(s, ctrl[t])
+        if (t + 1) % 3 == 0:
+            assert np.array_equal(s, traj[(t + 1) // 3 - 1])
+    assert np.array_equal(s, term)
+
+
+def test_permutation_invariance_and_ragged_sizes(gpu_vm, workloads):
+    s0, tab, pid = workloads.config3(1000, 40)
+    vm = gpu_vm(1e-3)
+    full = vm.rollout(s0, tab, path_id=pid)
+    perm = np.random.default_rng(5).permutation(1000)
+    assert np.array_equal(vm.rollout(s0[:, perm], tab, path_id=pid[perm]), full[:, perm])
+    for n in (1, 63, 64, 65, 257, 999):
+        assert np.array_equal(vm.rollout(s0[:, :n], tab, path_id=pid[:n]), full[:, :n])
+
+
+def test_lds_chunking_and_large_table_paths(gpu_vm, oracle):
+    """Shared table longer than one LDS chunk (H = 400, k = 12, fp64) and a table
+    too wide for LDS (P = 600) both equal the per-rollout expansion bit for bit."""
+    rng = np.random.default_rng(11)
+    vm = gpu_vm(5e-4)
+    for P, H, n in ((7, 400, 300), (600, 6, 1200)):
+        tab = np.empty((P, H, 12))
+        tab[:, :, 0:2] = rng.uniform(-0.1, 0.1, (P, H, 1))
+        tab[:, :, 2:4] = rng.uniform(-0.02, 0.02, (P, H, 2))
+        tab[:, :, 4:8] = rng.uniform(-100, 300, (P, H, 4))
+        tab[:, :, 8:12] = rng.uniform(0.5, 1.0, (P, H, 4))
+        pid = rng.integers(0, P, n).astype(np.int32)
+        s0 = np.zeros((12, n))
+        s0[0] = rng.uniform(10, 30, n)
+        s0[3:7] = s0[0] / 0.308309813617345
+        a = vm.rollout(s0, tab, path_id=pid)
+        b = vm.rollout(s0, np.ascontiguousarray(np.transpose(tab[pid], (1, 2, 0))))
+        assert np.array_equal(a, b)
+        want = oracle.rollout(oracle.default_params(), s0, tab, 5e-4, path_id=pid, nthreads=4)
+        assert parity(a, want, F64_TOL) <= 1e-8
+
+
+def test_mu_max_argument_k2(gpu_vm, oracle, workloads):
+    s0, ctrl = workloads.config2(8, 50)
+    mu = [0.9, 0.4, 0.7, 1.0]
+    got = gpu_vm(1e-3).rollout(s0, ctrl, mu_max=mu)
+    want = oracle.rollout(oracle.default_params(), s0, ctrl, 1e-3, mu_max=mu)
+    assert parity(got, want, F64_TOL) <= GUARD_F64
+    c12 = np.concatenate([np.repeat(ctrl[:, :1], 2, 1), np.zeros_like(ctrl[:, :1]).repeat(2, 1),
+                          np.repeat(ctrl[:, 1:2], 4, 1),
+                          np.broadcast_to(np.array(mu)[None, :, None], (50, 4, 64))], axis=1)
+    assert parity(gpu_vm(1e-3).rollout(s0, np.ascontiguousarray(c12)), want, F64_TOL) <= GUARD_F64
+
+
+def test_custom_vehicle_parameters(gpu_vm, pkg, oracle, workloads):
+    p = pkg.VehicleParameters(mf=1100.0, mr=900.0, L=3.1, T=1.6, hg=0.6, Jw=1.3, BFL=18.0, CFL=1.4)
+    p.BRL = p.BRR = 0.8 * p.BFL
+    p.CRL = p.CRR = 0.9 * p.CFL      # the under/oversteer experiment of vehicle_model.py:237-242
+    s0, ctrl = workloads.config2(8, 60)
+    s0[3:7] = 25.0 / p.rw
+    got = gpu_vm(1e-3, params=p).rollout(s0, ctrl)
+    want = oracle.rollout(oracle.params_from(p), s0, ctrl, 1e-3)
+    assert parity(got, want, F64_TOL) <= 1e-8
+
+
+def test_mpc_config5_shape_vs_oracle(gpu_vm, oracle, workloads):
+    E, C, H, dt = 48, 512, 50, 2e-3
+    ego, cand, goal = workloads.config5(E, C, H)
+    bc, bi, cost = gpu_vm(dt).mpc_argmin(ego, cand, goal, w_delta=workloads.MPC_W_DELTA, return_costs=True)
+    obc, obi, ocost = oracle.mpc_argmin(oracle.default_params(), ego.astype(np.float64),
+                                        cand.astype(np.float64), goal.astype(np.float64), dt,
+                                        workloads.MPC_W_DELTA, nthreads=oracle.max_threads(),
+                                        return_costs=True)
+    assert np.abs(cost - ocost).max() <= 1e-3
+    assert np.array_equal(bi, cost.argmin(axis=1))            # device argmin == argmin of its own costs
+    assert np.array_equal(bc, cost.min(axis=1))
+    assert (ocost[np.arange(E), bi] <= obc + 2e-4).all()      # and a true minimiser up to fp32 noise
+    agree = (bi == obi).mean()
+    print(f"\n  mpc: fp32 argmin agrees with fp64 oracle on {agree:.1%} of egos")
+    # odd candidate counts (block not full, > 1024 candidates strided)
+    for Cn in (1, 65, 1500):
+        ego2, cand2, goal2 = workloads.config5(5, Cn, 10)
+        b2c, b2i, c2 = gpu_vm(dt).mpc_argmin(ego2, cand2, goal2, return_costs=True)
+        assert np.array_equal(b2i, c2.argmin(axis=1)) and np.array_equal(b2c, c2.min(axis=1))
+
+
+def test_mpc_ties_and_disqualification(gpu_vm, workloads):
+    ego, cand, goal = workloads.config5(4, 128, 10, np.float64)
+    cand[:, :, 64:] = cand[:, :, :64]                          # every candidate twice
+    vm = gpu_vm(2e-3)
+    bc, bi, cost = vm.mpc_argmin(ego, cand, goal, return_costs=True)
+    assert (bi < 64).all() and np.array_equal(bi, cost.argmin(axis=1))
+    ego[0, 1] = 0.0
+    ego[2, 1] = 0.0                                           # vx = 0 -> division by zero -> non-finite
+    ego[3:7, 1] = 0.0
+    bc, bi = vm.mpc_argmin(ego, cand, goal)
+    assert bi[1] == -1 and np.isinf(bc[1]) and (bi[[0, 2, 3]] >= 0).all()
+
+
+def test_nonfinite_propagates_only_in_its_lane(gpu_vm, workloads):
+    s0, ctrl = workloads.config2(8, 20)
+    clean = gpu_vm(1e-3).rollout(s0, ctrl)
+    s0[0, 5] = 0.0
+    s0[2, 5] = 0.0                                             # U = wz = 0 -> vx = 0 (vehicle_model.py:284)
+    got = gpu_vm(1e-3).rollout(s0, ctrl)
+    assert not np.isfinite(got[:, 5]).all()
+    keep = np.arange(64) != 5
+    assert np.array_equal(got[:, keep], clean[:, keep])
+
+
+def test_empty_zero_horizon_and_errors(gpu_vm, pkg):
+    vm = gpu_vm(1e-3)
+    assert vm.rollout(np.zeros((12, 0)), np.zeros((5, 2, 0))).shape == (12, 0)
+    s0 = np.random.default_rng(0).normal(size=(12, 10)) + 20
+    assert np.array_equal(vm.rollout(s0, np.zeros((0, 2, 10))), s0)        # H = 0: identity
+    assert vm.step(np.zeros((12, 0)), np.zeros((2, 0))).shape == (12, 0)
+    with pytest.raises(ValueError):
+        vm.rollout(np.zeros((10, 4)), np.zeros((5, 2, 4)))
+    with pytest.raises(ValueError):
+        vm.rollout(np.zeros((12, 4)), np.zeros((5, 3, 4)))
+    with pytest.raises(ValueError):
+        vm.rollout(np.zeros((12, 4)), np.zeros((3, 5, 2)), path_id=[0, 1, 2, 3])   # id 3 >= P
+    with pytest.raises(ValueError):
+        vm.planar_model_RK4([1.0] * 9, [0] * 4, [1] * 4, [0] * 4, pkg.VehicleParameters(), 0, 0)
+    with pytest.raises(pkg.VdynError):
+        vm._handle(0).call("vdyn_rollout_f64_host", 4, 5, None, None, 2, 0, None, 0, 1e-3, None, None,
+                           None, 0)                                          # null buffers -> VDYN_ERR_ARG
+    with pytest.raises(pkg.VdynError):
+        pkg.VehicleModel(1.0, 0.7, 1e-3, device=99).step(np.zeros((12, 1)), np.zeros((2, 1)))
+
+
+def test_torch_stream_and_dtypes(gpu_vm, workloads):
+    import torch
+    s0, ctrl = workloads.config2(8, 30)
+    vm = gpu_vm(1e-3)
+    dev = torch.device("cuda:0")
+    host = vm.rollout(s0, ctrl)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t = vm.rollout(torch.from_numpy(s0).to(dev), torch.from_numpy(ctrl).to(dev))
+    side.synchronize()
+    assert np.array_equal(t.cpu().numpy(), host)
+    t32 = vm.rollout(torch.from_numpy(s0).to(dev).float(), torch.from_numpy(ctrl).to(dev).float())
+    assert t32.dtype == torch.float32
+    assert np.array_equal(t32.cpu().numpy(), vm.rollout(s0.astype(np.float32), ctrl.astype(np.float32)))
