@@ -13,12 +13,16 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libvdyn_hip.so")
+# VDYN_LIB_PATH: load/build an alternative in-tree build (A/B experiments only)
+LIB_PATH = os.environ.get("VDYN_LIB_PATH") or os.path.join(PKG_DIR, "libvdyn_hip.so")
 SOURCES = ["vdyn_kernels.hip", "vdyn_capi.hip"]
 HEADERS = [os.path.join(CSRC, "vdyn_device.hpp"), os.path.join(CSRC, "vdyn_internal.hpp"),
            os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+               "-fno-fast-math", "-Wall", "-Wno-unused-function",
+               # packed fp32 VALU issues at half rate on gfx950, so SLP-packing scalar
+               # fp32 math only adds v_mov shuffles: measured 5 % slower (profiles/README.md)
+               "-fno-slp-vectorize"]
 
 
 def hipcc_path():

@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "vdyn_fastmath.hpp"
+
 namespace vdyn {
 
 // Wave-uniform constants, passed by value as a kernel argument (SGPR-resident:
@@ -24,6 +26,7 @@ struct DevParams {
     T Fz0F, Fz0R;               // static normal loads (:245-248)
     T DfzxL, DfzxR, DfzyF, DfzyR;  // load-transfer coefficients (:250-253)
     T B[4], C[4];               // Pacejka B, C for FL, FR, RL, RR (:303-306)
+    T invB[4];                  // 1/B: 1/(B s) = (1/s)(1/B) feeds atan's x > 1 branch for free
     T mu[4];                    // mu_max used by k = 2 controls (drive.py:142: [1,1,1,1])
 };
 
@@ -31,25 +34,52 @@ struct DevParams {
 template <typename T> struct Math;
 
 template <> struct Math<float> {
-    static __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
-    static __device__ __forceinline__ float atan(float x) { return ::atanf(x); }
-    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
-    static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
-    static __device__ __forceinline__ float rsqrt(float x) { return 1.0f / ::sqrtf(x); }
+    // bounded-range straight-line versions (vdyn_fastmath.hpp)
+    static __device__ __forceinline__ float sin_pacejka(float y) { return fm::sin_mid(y); }
+    static __device__ __forceinline__ float atan_pos(float x, float inv_x) { return fm::atan_pos(x, inv_x); }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { fm::sincos_any(x, s, c); }
+    static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
     static __device__ __forceinline__ float abs(float x) { return ::fabsf(x); }
+    // sin d, cos d for a small stage increment d of the yaw angle; `ok` = series valid
+    static __device__ __forceinline__ bool small_sincos(float d, float *s, float *c)
+    {
+        const float u = d * d;
+        *s = fmaf(d * u, fmaf(u, fmaf(u, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), d);
+        *c = fmaf(u, fmaf(u, fmaf(u, fmaf(u, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+        return ::fabsf(d) <= 0.25f;
+    }
 };
 
 template <> struct Math<double> {
-    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
-    static __device__ __forceinline__ double atan(double x) { return ::atan(x); }
+    static __device__ __forceinline__ double sin_pacejka(double y) { return ::sin(y); }
+    static __device__ __forceinline__ double atan_pos(double x, double) { return ::atan(x); }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
     static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
+    static __device__ __forceinline__ bool small_sincos(double d, double *s, double *c)
+    {
+        const double u = d * d;
+        double ps = -1.0 / 39916800.0;                 // d^11 / 11!
+        ps = ::fma(ps, u, 1.0 / 362880.0);
+        ps = ::fma(ps, u, -1.0 / 5040.0);
+        ps = ::fma(ps, u, 1.0 / 120.0);
+        ps = ::fma(ps, u, -1.0 / 6.0);
+        *s = ::fma(d * u, ps, d);
+        double pc = 1.0 / 479001600.0;                 // d^12 / 12!
+        pc = ::fma(pc, u, -1.0 / 3628800.0);
+        pc = ::fma(pc, u, 1.0 / 40320.0);
+        pc = ::fma(pc, u, -1.0 / 720.0);
+        pc = ::fma(pc, u, 1.0 / 24.0);
+        pc = ::fma(pc, u, -0.5);
+        *c = ::fma(pc, u, 1.0);
+        return ::fabs(d) <= 0.0625;
+    }
 };
 
 // ---- per-step invariants (frozen over the four RK4 stages, :429-436) ----------------
@@ -95,7 +125,7 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
 //   :274-281 rotation, :284-293 slips (quirk Q4: signed vx for s_x, |vx| for s_y),
 //   :296-299 combined slip, :303-348 Pacejka + split, :351-373 forces.
 template <typename T, bool STEERED>
-__device__ __forceinline__ void tire_force(T B, T C, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
+__device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
                                            T &fx, T &fy, T &fxt, T &fyt, T &s_out)
 {
     using M = Math<T>;
@@ -118,7 +148,7 @@ __device__ __forceinline__ void tire_force(T B, T C, T rw, T vxc, T vyc, T w, T 
     // quirk Q5: when s == 0 the reference evaluates D sin(C atan(B s_x)) on an
     // s_x whose square underflowed; sin(C atan(B e)) == C B e to the last bit
     // for such e, so the s -> 0 limit C*B of sin(C atan(B s))/s is exact there.
-    const T g = (s2 == T(0)) ? C * B : M::sin(C * M::atan(B * s)) * rs;
+    const T g = (s2 == T(0)) ? C * B : M::sin_pacejka(C * M::atan_pos(B * s, rs * invB)) * rs;
     const T gf = g * muFz;
     fxt = sx * gf;
     fyt = sy * gf;
@@ -138,13 +168,12 @@ struct Outputs18 {
     T v[18];
 };
 
-// State derivative, vehicle_model.py:220-425.  s[10] = U,V,wz,wFL,wFR,wRL,wRR,yaw,x,y.
-// Returns k[10] and the body accelerations axc, ayc (:413-414).
+// State derivative, vehicle_model.py:220-425.  s[10] = U,V,wz,wFL,wFR,wRL,wRR,yaw,x,y;
+// (sy, cy) = sin, cos of s[7].  Returns k[10] and the body accelerations axc, ayc (:413-414).
 template <typename T, bool REAR, bool DIAG>
 __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepInv<T> &c, const T s[10],
-                                             T k[10], T &axc, T &ayc, Outputs18<T> *out)
+                                             T sy, T cy, T k[10], T &axc, T &ayc, Outputs18<T> *out)
 {
-    using M = Math<T>;
     const T U = s[0], V = s[1], wz = s[2];
     // :261-271 (quirk Q8: left wheels at -T/2)
     const T hTw = P.half_T * wz;
@@ -152,13 +181,13 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     const T vFy = V + P.a * wz, vRy = V - P.b * wz;
 
     T fx[4], fy[4], fxt[4], fyt[4], sl[4];
-    tire_force<T, true>(P.B[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
+    tire_force<T, true>(P.B[0], P.invB[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
                         fx[0], fy[0], fxt[0], fyt[0], sl[0]);
-    tire_force<T, true>(P.B[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
+    tire_force<T, true>(P.B[1], P.invB[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
                         fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-    tire_force<T, REAR>(P.B[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
+    tire_force<T, REAR>(P.B[2], P.invB[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
                         fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-    tire_force<T, REAR>(P.B[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
+    tire_force<T, REAR>(P.B[3], P.invB[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
                         fx[3], fy[3], fxt[3], fyt[3], sl[3]);
 
     // :376-385
@@ -174,8 +203,6 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     k[5] = (c.tq[2] - P.rw * fx[2]) * P.inv_Jw;
     k[6] = (c.tq[3] - P.rw * fx[3]) * P.inv_Jw;
     k[7] = wz;
-    T sy, cy;
-    M::sincos(s[7], &sy, &cy);  // quirk Q7: yaw is never wrapped -> full-range sincos
     k[8] = U * cy - V * sy;
     k[9] = U * sy + V * cy;
     axc = Udot - V * wz;  // :413
@@ -207,13 +234,31 @@ __device__ __forceinline__ void rk4_step(const DevParams<T> &P, T s[10], T &ax, 
     T k[10], acc[10], st[10], a1, a2, asx, asy;
     Outputs18<T> o, osum;
 
-    planar_deriv<T, REAR, DIAG>(P, c, s, k, a1, a2, &o);          // K1 (:429)
+    // sin / cos of the stage yaw: one full evaluation per step (quirk Q7: yaw is
+    // never wrapped), then the stage increments d = yaw_stage - yaw are rotated
+    // in with a short series; a large increment falls back to the full evaluation.
+    using M = Math<T>;
+    T sy0, cy0, sy, cy, sdl, cdl;
+    M::sincos(s[7], &sy0, &cy0);
+#define VDYN_STAGE_SINCOS(dexpr)                                        \
+    do {                                                                \
+        const T d_ = (dexpr);                                           \
+        if (M::small_sincos(d_, &sdl, &cdl)) {                          \
+            sy = sy0 * cdl + cy0 * sdl;                                 \
+            cy = cy0 * cdl - sy0 * sdl;                                 \
+        } else {                                                        \
+            M::sincos(st[7], &sy, &cy);                                 \
+        }                                                               \
+    } while (0)
+
+    planar_deriv<T, REAR, DIAG>(P, c, s, sy0, cy0, k, a1, a2, &o);  // K1 (:429)
     asx = a1; asy = a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = k[i]; st[i] = s[i] + hh * k[i]; }
     if (DIAG) osum = o;
 
-    planar_deriv<T, REAR, DIAG>(P, c, st, k, a1, a2, &o);         // K2 (:431)
+    VDYN_STAGE_SINCOS(hh * k[7]);
+    planar_deriv<T, REAR, DIAG>(P, c, st, sy, cy, k, a1, a2, &o);   // K2 (:431)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; st[i] = s[i] + hh * k[i]; }
@@ -222,7 +267,8 @@ __device__ __forceinline__ void rk4_step(const DevParams<T> &P, T s[10], T &ax, 
         for (int i = 0; i < 18; ++i) osum.v[i] += T(2) * o.v[i];
     }
 
-    planar_deriv<T, REAR, DIAG>(P, c, st, k, a1, a2, &o);         // K3 (:433)
+    VDYN_STAGE_SINCOS(hh * k[7]);
+    planar_deriv<T, REAR, DIAG>(P, c, st, sy, cy, k, a1, a2, &o);   // K3 (:433)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; st[i] = s[i] + h * k[i]; }
@@ -231,7 +277,9 @@ __device__ __forceinline__ void rk4_step(const DevParams<T> &P, T s[10], T &ax, 
         for (int i = 0; i < 18; ++i) osum.v[i] += T(2) * o.v[i];
     }
 
-    planar_deriv<T, REAR, DIAG>(P, c, st, k, a1, a2, &o);         // K4 (:435)
+    VDYN_STAGE_SINCOS(h * k[7]);
+#undef VDYN_STAGE_SINCOS
+    planar_deriv<T, REAR, DIAG>(P, c, st, sy, cy, k, a1, a2, &o);   // K4 (:435)
     asx += a1; asy += a2;
     const T h6 = h * T(1.0 / 6.0), sixth = T(1.0 / 6.0);
 #pragma unroll

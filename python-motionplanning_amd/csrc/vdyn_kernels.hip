@@ -136,14 +136,14 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
     StepInv<T> inv;
     make_step_inv<T, true>(P, c.delta, c.tq, c.mu, acc_prev[r], acc_prev[n + r], inv);
     Outputs18<T> o;
-    planar_deriv<T, true, true>(P, inv, s, k, axc, ayc, &o);
+    T sy, cy;
+    Math<T>::sincos(s[7], &sy, &cy);
+    planar_deriv<T, true, true>(P, inv, s, sy, cy, k, axc, ayc, &o);
 #pragma unroll
     for (int i = 0; i < 10; ++i) state_dot[(int64_t)i * n + r] = k[i];
     acc[r] = axc;
     acc[n + r] = ayc;
     if (aux != nullptr) {
-        T sy, cy;
-        Math<T>::sincos(s[7], &sy, &cy);
         aux[r] = s[0] * cy - s[1] * sy;          // vx, :410
         aux[n + r] = s[1] * sy + s[0] * cy;      // vy, :411 (the reference's own sin/cos mix-up)
         aux[2 * n + r] = axc * cy - ayc * sy;    // ax, :415
@@ -236,6 +236,7 @@ DevParams<T> make_dev_params(const VdynParams &p, const double *mu4)
     for (int i = 0; i < 4; ++i) {
         d.B[i] = (T)p.B[i];
         d.C[i] = (T)p.C[i];
+        d.invB[i] = (T)(1.0 / p.B[i]);
         d.mu[i] = mu4 ? (T)mu4[i] : (T)1;
     }
     return d;
