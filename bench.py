@@ -124,7 +124,7 @@ def main():
     s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
     pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
-    gathered = torch.empty((world, 12, N_PER_GPU), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * 12, N_PER_GPU), dtype=torch.float32, device=dev) if world > 1 else None
     del s0_all, pid_all
 
     kern_ev = []
