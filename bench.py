@@ -229,6 +229,14 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = timed_launches(lambda: vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA), 5, torch)
     ex["config5_mpc_1024x512x50_f32"] = {"steps_per_s": E * C * H / t, "kernel_ms": t * 1e3,
                                          "rollouts_per_s": E * C / t}
+    # the same workload through the HOST-pointer ABI (staging copies over PCIe included)
+    s0_h, pid_h = s0.cpu().numpy(), pid.cpu().numpy()
+    vm.rollout(s0_h, tab, path_id=pid_h)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        vm.rollout(s0_h, tab, path_id=pid_h)
+    t = (time.perf_counter() - t0) / 5
+    ex["host_abi_pcie_inclusive_f32"] = {"steps_per_s": n / t, "ms": t * 1e3}
     # occupancy sweep of the main kernel: where the chip fills up
     sweep = {}
     for mult in (2, 4, 8):

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs of profiles/collect.sh into
+<out>/summary/<tag>_kernel_stats.csv (verbatim stats of our kernels) and
+<out>/summary/<tag>_pmc_summary.json (per-launch counter averages of the rollout kernel).
+
+HBM traffic follows MI355X_MICROARCH.md section HBM: bytes = FETCH_SIZE * 1024 and
+WRITE_SIZE * 1024 (the counters are in KiB); on gfx950 FETCH_SIZE tallies 128-B
+requests of wide (16 B/lane) coalesced reads at 64 B, i.e. reads HALF the bytes of such
+a stream.  This kernel's global reads are dword-per-lane loads (256 B per wave
+instruction), a width the guide calls uncalibrated, so both the raw and the x2-corrected
+read figures are reported and the corrected one is used for `hbm_bytes_per_launch`
+(an upper bound on the truth)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+KERNEL = "rollout_kernel"
+os.makedirs(os.path.join(out, "summary"), exist_ok=True)
+
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+summary = {"tag": tag, "kernel": None}
+ks = find("kt", "*kernel_stats.csv")
+if ks:
+    rows = list(csv.DictReader(open(ks)))
+    ours = [r for r in rows if "vdyn::" in r["Name"]]
+    with open(os.path.join(out, "summary", f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(ours + [r for r in rows if "vdyn::" not in r["Name"]][:5])
+    for r in ours:
+        if KERNEL in r["Name"]:
+            summary["kernel"] = r["Name"].split("(")[0]
+            summary["calls"] = int(r["Calls"])
+            summary["avg_ns"] = float(r["AverageNs"])
+            summary["min_ns"] = float(r["MinNs"])
+            summary["max_ns"] = float(r["MaxNs"])
+kt = find("kt", "*kernel_trace.csv")
+if kt:
+    for r in csv.DictReader(open(kt)):
+        if KERNEL in r["Kernel_Name"]:
+            summary["vgpr"] = int(r["VGPR_Count"])
+            summary["accum_vgpr"] = int(r["Accum_VGPR_Count"])
+            summary["sgpr"] = int(r["SGPR_Count"])
+            summary["lds_bytes"] = int(r["LDS_Block_Size"])
+            summary["scratch_bytes"] = int(r["Scratch_Size"])
+            summary["grid"] = int(r["Grid_Size_X"])
+            summary["workgroup"] = int(r["Workgroup_Size_X"])
+            break
+
+counters = defaultdict(list)
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    cc = find(sub, "*counter_collection.csv")
+    if not cc:
+        continue
+    per_dispatch = defaultdict(float)
+    for r in csv.DictReader(open(cc)):
+        if KERNEL in r["Kernel_Name"]:
+            per_dispatch[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (_, name), v in per_dispatch.items():
+        counters[name].append(v)
+summary["counters_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
+c = summary["counters_per_launch"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    summary["fetch_bytes_raw"] = c["FETCH_SIZE"] * 1024
+    summary["fetch_bytes_x2_gfx950"] = c["FETCH_SIZE"] * 2048
+    summary["write_bytes"] = c["WRITE_SIZE"] * 1024
+    summary["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024
+if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
+    summary["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    summary["valu_insts_per_wave_per_rk4_step"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / 200.0
+    if "SQ_WAVE_CYCLES" in c:  # quad-cycles (MI355X_MICROARCH.md cycle-constants table)
+        summary["wave_cycles_per_valu_inst"] = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_INSTS_VALU"]
+with open(os.path.join(out, "summary", f"{tag}_pmc_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+print(json.dumps(summary, indent=1))
