@@ -9,6 +9,16 @@
 // the three divisions and the square root per wheel become one reciprocal and
 // one reciprocal square root; the Pacejka split mu_x = s_x mu / s is evaluated
 // as s_x * (sin(C atan(B s)) / s) with mu_max folded into the normal load.
+//
+// Two instantiations of the step exist.  FAST (SAFE = false) is straight-line
+// code with no branch at all: a lone wave per SIMD pays tens of cycles for every
+// taken branch, and 30-odd "skip the rare fallback" branches per step cost ~17 %
+// of the kernel (rocprofv3 SQ_WAIT_ANY, profiles/README.md).  Its trigonometry
+// is valid on a bounded range; each lane records whether it stayed inside it,
+// and a lane that did not (|yaw| or |delta| > 2^16 rad, a stage yaw increment
+// > pi/4) is re-integrated for that step by SAFE (SAFE = true: ROCm device
+// library functions, full range) behind one wave-uniform, normally-not-taken
+// branch.  A lane's result never depends on what other lanes did.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,61 +36,72 @@ struct DevParams {
     T Fz0F, Fz0R;               // static normal loads (:245-248)
     T DfzxL, DfzxR, DfzyF, DfzyR;  // load-transfer coefficients (:250-253)
     T B[4], C[4];               // Pacejka B, C for FL, FR, RL, RR (:303-306)
-    T invB[4];                  // 1/B: 1/(B s) = (1/s)(1/B) feeds atan's x > 1 branch for free
+    T invB[4];                  // 1/B: 1/(B s) = (1/s)(1/B) feeds atan's |x| > 1 branch for free
     T mu[4];                    // mu_max used by k = 2 controls (drive.py:142: [1,1,1,1])
 };
 
-// ---- scalar math wrappers -------------------------------------------------------
-template <typename T> struct Math;
+// ---- scalar math, by type and by path ------------------------------------------------
+template <typename T, bool SAFE> struct Math;
 
-template <> struct Math<float> {
-    // bounded-range straight-line versions (vdyn_fastmath.hpp)
-    static __device__ __forceinline__ float sin_pacejka(float y) { return fm::sin_mid(y); }
-    static __device__ __forceinline__ float atan_pos(float x, float inv_x) { return fm::atan_pos(x, inv_x); }
-    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { fm::sincos_any(x, s, c); }
+template <> struct Math<float, false> {
+    static constexpr bool kHasRangeLimit = true;
     static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
-    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
-    static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
-    static __device__ __forceinline__ float abs(float x) { return ::fabsf(x); }
-    // sin d, cos d for a small stage increment d of the yaw angle; `ok` = series valid
-    static __device__ __forceinline__ bool small_sincos(float d, float *s, float *c)
+    // sin(C atan(x)), inv_x = 1/x
+    static __device__ __forceinline__ float sin_c_atan(float C, float x, float inv_x)
     {
-        const float u = d * d;
-        *s = fmaf(d * u, fmaf(u, fmaf(u, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), d);
-        *c = fmaf(u, fmaf(u, fmaf(u, fmaf(u, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
-        return ::fabsf(d) <= 0.25f;
+        return fm::sin_mid(C * fm::atan_rcp(x, inv_x));
+    }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c, bool &ok)
+    {
+        fm::sincos_mid(x, s, c);
+        ok = ok && (::fabsf(x) <= fm::kSincosMidLimit);
+    }
+    // sin, cos of (yaw + d) from sin, cos of yaw: rotate by the small increment
+    static __device__ __forceinline__ void stage_sincos(float sy0, float cy0, float, float d, float *s,
+                                                        float *c, bool &ok)
+    {
+        float sd, cd;
+        fm::sincos_kernel(d, &sd, &cd);
+        *s = ::fmaf(sy0, cd, cy0 * sd);
+        *c = ::fmaf(cy0, cd, -sy0 * sd);
+        ok = ok && (::fabsf(d) <= fm::kSincosKernelLimit);
     }
 };
 
-template <> struct Math<double> {
-    static __device__ __forceinline__ double sin_pacejka(double y) { return ::sin(y); }
-    static __device__ __forceinline__ double atan_pos(double x, double) { return ::atan(x); }
-    static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
-    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
-    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-    static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
-    static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
-    static __device__ __forceinline__ bool small_sincos(double d, double *s, double *c)
+template <> struct Math<float, true> {
+    static constexpr bool kHasRangeLimit = false;
+    static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
+    static __device__ __forceinline__ float sin_c_atan(float C, float x, float) { return ::sinf(C * ::atanf(x)); }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c, bool &) { ::sincosf(x, s, c); }
+    static __device__ __forceinline__ void stage_sincos(float, float, float yaw, float, float *s, float *c, bool &)
     {
-        const double u = d * d;
-        double ps = -1.0 / 39916800.0;                 // d^11 / 11!
-        ps = ::fma(ps, u, 1.0 / 362880.0);
-        ps = ::fma(ps, u, -1.0 / 5040.0);
-        ps = ::fma(ps, u, 1.0 / 120.0);
-        ps = ::fma(ps, u, -1.0 / 6.0);
-        *s = ::fma(d * u, ps, d);
-        double pc = 1.0 / 479001600.0;                 // d^12 / 12!
-        pc = ::fma(pc, u, -1.0 / 3628800.0);
-        pc = ::fma(pc, u, 1.0 / 40320.0);
-        pc = ::fma(pc, u, -1.0 / 720.0);
-        pc = ::fma(pc, u, 1.0 / 24.0);
-        pc = ::fma(pc, u, -0.5);
-        *c = ::fma(pc, u, 1.0);
-        return ::fabs(d) <= 0.0625;
+        ::sincosf(yaw, s, c);
     }
 };
+
+template <bool SAFE> struct Math<double, SAFE> {
+    static constexpr bool kHasRangeLimit = false;
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double sin_c_atan(double C, double x, double) { return ::sin(C * ::atan(x)); }
+    static __device__ __forceinline__ void sincos(double x, double *s, double *c, bool &) { ::sincos(x, s, c); }
+    static __device__ __forceinline__ void stage_sincos(double, double, double yaw, double, double *s, double *c,
+                                                        bool &)
+    {
+        ::sincos(yaw, s, c);
+    }
+};
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return ::fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return ::fma(a, b, c); }
+__device__ __forceinline__ float abs_t(float a) { return ::fabsf(a); }
+__device__ __forceinline__ double abs_t(double a) { return ::fabs(a); }
+__device__ __forceinline__ float tiny_t(float) { return 1e-30f; }     // sqrt = 1e-15: (B s)^2 below fp32 ulp
+__device__ __forceinline__ double tiny_t(double) { return 1e-280; }   // sqrt = 1e-140
+__device__ __forceinline__ float sqrt_t(float a) { return ::sqrtf(a); }
+__device__ __forceinline__ double sqrt_t(double a) { return ::sqrt(a); }
 
 // ---- per-step invariants (frozen over the four RK4 stages, :429-436) ----------------
 template <typename T>
@@ -91,22 +112,24 @@ struct StepInv {
     T tq[4];         // wheel torques (:226)
 };
 
-// REAR = false: rear steering angles are exactly 0 (k = 2 controls), so the
-// rear rotations are the identity and are skipped (x*1 + y*0 == x in IEEE).
-template <typename T, bool REAR>
+// K2 = true: the drive.py:142-143 pattern -- delta[1] == delta[0], rear angles exactly
+// 0, so one sincos serves the front axle and the rear rotations are the identity
+// (x*1 + y*0 == x in IEEE) and are skipped.
+template <typename T, bool K2, bool SAFE>
 __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T delta[4], const T tq[4],
-                                              const T mu[4], T ax_prev, T ay_prev, StepInv<T> &c)
+                                              const T mu[4], T ax_prev, T ay_prev, StepInv<T> &c, bool &ok)
 {
-    using M = Math<T>;
-    M::sincos(delta[0], &c.sd[0], &c.cd[0]);
-    if (delta[1] == delta[0]) { c.sd[1] = c.sd[0]; c.cd[1] = c.cd[0]; }
-    else M::sincos(delta[1], &c.sd[1], &c.cd[1]);
-    if (REAR) {
-        M::sincos(delta[2], &c.sd[2], &c.cd[2]);
-        M::sincos(delta[3], &c.sd[3], &c.cd[3]);
-    } else {
+    using M = Math<T, SAFE>;
+    M::sincos(delta[0], &c.sd[0], &c.cd[0], ok);
+    if (K2) {
+        c.sd[1] = c.sd[0];
+        c.cd[1] = c.cd[0];
         c.sd[2] = c.sd[3] = T(0);
         c.cd[2] = c.cd[3] = T(1);
+    } else {
+        M::sincos(delta[1], &c.sd[1], &c.cd[1], ok);
+        M::sincos(delta[2], &c.sd[2], &c.cd[2], ok);
+        M::sincos(delta[3], &c.sd[3], &c.cd[3], ok);
     }
     // :255-258
     c.Fz[0] = P.Fz0F - P.DfzxL * ax_prev - P.DfzyF * ay_prev;
@@ -124,11 +147,11 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
 // (fxt, fyt), chassis-frame force (fx, fy) and combined slip s.
 //   :274-281 rotation, :284-293 slips (quirk Q4: signed vx for s_x, |vx| for s_y),
 //   :296-299 combined slip, :303-348 Pacejka + split, :351-373 forces.
-template <typename T, bool STEERED>
+template <typename T, bool STEERED, bool SAFE>
 __device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
                                            T &fx, T &fy, T &fxt, T &fyt, T &s_out)
 {
-    using M = Math<T>;
+    using M = Math<T, SAFE>;
     T vx, vy;
     if (STEERED) {
         vx = vxc * cd + vyc * sd;
@@ -140,15 +163,19 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc,
     const T rvx = M::rcp(vx);
     // rw*w/vx - 1 == (rw*w - vx)/vx; the fused form rounds the small
     // difference once instead of cancelling two O(1) quantities.
-    const T sx = M::fma(rw, w, -vx) * rvx;
-    const T sy = -vy * M::abs(rvx);
+    const T sx = fma_t(rw, w, -vx) * rvx;
+    const T sy = -vy * abs_t(rvx);
     const T s2 = sx * sx + sy * sy;
-    const T rs = M::rsqrt(s2);
-    const T s = s2 * rs;
-    // quirk Q5: when s == 0 the reference evaluates D sin(C atan(B s_x)) on an
-    // s_x whose square underflowed; sin(C atan(B e)) == C B e to the last bit
-    // for such e, so the s -> 0 limit C*B of sin(C atan(B s))/s is exact there.
-    const T g = (s2 == T(0)) ? C * B : M::sin_pacejka(C * M::atan_pos(B * s, rs * invB)) * rs;
+    // quirk Q5 (the reference's `s != 0` branch, :309-348), without a branch: clamp
+    // s^2 from below by a tiny constant.  For s^2 <= tiny, sin(C atan(B s))/s equals
+    // its s -> 0 limit C*B to the last bit, and that is also what the reference's
+    // fallback D sin(C atan(B s_x)) evaluates to on an s_x whose square underflowed;
+    // with the clamp the regular formula produces exactly that limit (and 0 forces
+    // for s_x = s_y = 0) while 1/s stays finite.
+    const T s2c = s2 > tiny_t(T(0)) ? s2 : tiny_t(T(0));
+    const T rs = M::rsqrt(s2c);
+    const T s = s2c * rs;
+    const T g = M::sin_c_atan(C, B * s, rs * invB) * rs;
     const T gf = g * muFz;
     fxt = sx * gf;
     fyt = sy * gf;
@@ -159,7 +186,7 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc,
         fx = fxt;
         fy = fyt;
     }
-    s_out = (s2 == T(0)) ? T(0) : s;
+    s_out = s2 * rs;  // == s, and exactly 0 when the slip is exactly 0
 }
 
 // Diagnostics of one derivative evaluation (vehicle_model.py:420-423 order).
@@ -170,7 +197,7 @@ struct Outputs18 {
 
 // State derivative, vehicle_model.py:220-425.  s[10] = U,V,wz,wFL,wFR,wRL,wRR,yaw,x,y;
 // (sy, cy) = sin, cos of s[7].  Returns k[10] and the body accelerations axc, ayc (:413-414).
-template <typename T, bool REAR, bool DIAG>
+template <typename T, bool K2, bool DIAG, bool SAFE>
 __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepInv<T> &c, const T s[10],
                                              T sy, T cy, T k[10], T &axc, T &ayc, Outputs18<T> *out)
 {
@@ -181,14 +208,14 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     const T vFy = V + P.a * wz, vRy = V - P.b * wz;
 
     T fx[4], fy[4], fxt[4], fyt[4], sl[4];
-    tire_force<T, true>(P.B[0], P.invB[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
-                        fx[0], fy[0], fxt[0], fyt[0], sl[0]);
-    tire_force<T, true>(P.B[1], P.invB[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
-                        fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-    tire_force<T, REAR>(P.B[2], P.invB[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
-                        fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-    tire_force<T, REAR>(P.B[3], P.invB[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
-                        fx[3], fy[3], fxt[3], fyt[3], sl[3]);
+    tire_force<T, true, SAFE>(P.B[0], P.invB[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
+                              fx[0], fy[0], fxt[0], fyt[0], sl[0]);
+    tire_force<T, true, SAFE>(P.B[1], P.invB[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
+                              fx[1], fy[1], fxt[1], fyt[1], sl[1]);
+    tire_force<T, !K2, SAFE>(P.B[2], P.invB[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
+                             fx[2], fy[2], fxt[2], fyt[2], sl[2]);
+    tire_force<T, !K2, SAFE>(P.B[3], P.invB[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
+                             fx[3], fy[3], fxt[3], fyt[3], sl[3]);
 
     // :376-385
     const T Udot = P.inv_m * (fx[0] + fx[1] + fx[2] + fx[3]) + V * wz;
@@ -220,81 +247,93 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     }
 }
 
-// Classic RK4 with frozen inputs, vehicle_model.py:427-445.  Updates s[10] in
-// place and replaces (ax, ay) by the 1-2-2-1 averages of axc, ayc (:442-443).
-// DIAG: also returns state_dot (:440) and the averaged outputs (:441).
-template <typename T, bool REAR, bool DIAG>
-__device__ __forceinline__ void rk4_step(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
-                                         const T tq[4], const T mu[4], T h, T *state_dot,
-                                         Outputs18<T> *outputs)
+// Classic RK4 with frozen inputs, vehicle_model.py:427-445: s[10], (ax, ay) ->
+// sn[10], (axn, ayn), the latter the 1-2-2-1 averages of axc, ayc (:442-443).
+// DIAG: also state_dot (:440) and the averaged outputs (:441).
+// Returns false for a lane that left the validated range of the FAST path.
+template <typename T, bool K2, bool DIAG, bool SAFE>
+__device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T ax, T ay, const T delta[4],
+                                         const T tq[4], const T mu[4], T h, T sn[10], T &axn, T &ayn,
+                                         T *state_dot, Outputs18<T> *outputs)
 {
+    using M = Math<T, SAFE>;
+    bool ok = true;
     StepInv<T> c;
-    make_step_inv<T, REAR>(P, delta, tq, mu, ax, ay, c);
+    make_step_inv<T, K2, SAFE>(P, delta, tq, mu, ax, ay, c, ok);
     const T hh = T(0.5) * h;
     T k[10], acc[10], st[10], a1, a2, asx, asy;
     Outputs18<T> o, osum;
 
     // sin / cos of the stage yaw: one full evaluation per step (quirk Q7: yaw is
-    // never wrapped), then the stage increments d = yaw_stage - yaw are rotated
-    // in with a short series; a large increment falls back to the full evaluation.
-    using M = Math<T>;
-    T sy0, cy0, sy, cy, sdl, cdl;
-    M::sincos(s[7], &sy0, &cy0);
-#define VDYN_STAGE_SINCOS(dexpr)                                        \
-    do {                                                                \
-        const T d_ = (dexpr);                                           \
-        if (M::small_sincos(d_, &sdl, &cdl)) {                          \
-            sy = sy0 * cdl + cy0 * sdl;                                 \
-            cy = cy0 * cdl - sy0 * sdl;                                 \
-        } else {                                                        \
-            M::sincos(st[7], &sy, &cy);                                 \
-        }                                                               \
-    } while (0)
+    // never wrapped), then stages 2-4 rotate by their increment d = yaw_stage - yaw.
+    T sy0, cy0, sy, cy;
+    M::sincos(s[7], &sy0, &cy0, ok);
 
-    planar_deriv<T, REAR, DIAG>(P, c, s, sy0, cy0, k, a1, a2, &o);  // K1 (:429)
+    planar_deriv<T, K2, DIAG, SAFE>(P, c, s, sy0, cy0, k, a1, a2, &o);       // K1 (:429)
     asx = a1; asy = a2;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { acc[i] = k[i]; st[i] = s[i] + hh * k[i]; }
+    for (int i = 0; i < 10; ++i) { acc[i] = k[i]; st[i] = fma_t(hh, k[i], s[i]); }
     if (DIAG) osum = o;
 
-    VDYN_STAGE_SINCOS(hh * k[7]);
-    planar_deriv<T, REAR, DIAG>(P, c, st, sy, cy, k, a1, a2, &o);   // K2 (:431)
+    M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
+    planar_deriv<T, K2, DIAG, SAFE>(P, c, st, sy, cy, k, a1, a2, &o);        // K2 (:431)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; st[i] = s[i] + hh * k[i]; }
+    for (int i = 0; i < 10; ++i) { acc[i] = fma_t(T(2), k[i], acc[i]); st[i] = fma_t(hh, k[i], s[i]); }
     if (DIAG) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) osum.v[i] += T(2) * o.v[i];
     }
 
-    VDYN_STAGE_SINCOS(hh * k[7]);
-    planar_deriv<T, REAR, DIAG>(P, c, st, sy, cy, k, a1, a2, &o);   // K3 (:433)
+    M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
+    planar_deriv<T, K2, DIAG, SAFE>(P, c, st, sy, cy, k, a1, a2, &o);        // K3 (:433)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { acc[i] += T(2) * k[i]; st[i] = s[i] + h * k[i]; }
+    for (int i = 0; i < 10; ++i) { acc[i] = fma_t(T(2), k[i], acc[i]); st[i] = fma_t(h, k[i], s[i]); }
     if (DIAG) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) osum.v[i] += T(2) * o.v[i];
     }
 
-    VDYN_STAGE_SINCOS(h * k[7]);
-#undef VDYN_STAGE_SINCOS
-    planar_deriv<T, REAR, DIAG>(P, c, st, sy, cy, k, a1, a2, &o);   // K4 (:435)
+    M::stage_sincos(sy0, cy0, st[7], h * k[7], &sy, &cy, ok);
+    planar_deriv<T, K2, DIAG, SAFE>(P, c, st, sy, cy, k, a1, a2, &o);        // K4 (:435)
     asx += a1; asy += a2;
     const T h6 = h * T(1.0 / 6.0), sixth = T(1.0 / 6.0);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         acc[i] += k[i];
-        s[i] += h6 * acc[i];                                       // :438
+        sn[i] = fma_t(h6, acc[i], s[i]);                                     // :438
     }
-    ax = asx * sixth;                                              // :442
-    ay = asy * sixth;                                              // :443
+    axn = asx * sixth;                                                       // :442
+    ayn = asy * sixth;                                                       // :443
     if (DIAG) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) state_dot[i] = acc[i] * sixth;        // :440
+        for (int i = 0; i < 10; ++i) state_dot[i] = acc[i] * sixth;                 // :440
 #pragma unroll
         for (int i = 0; i < 18; ++i) outputs->v[i] = (osum.v[i] + o.v[i]) * sixth;  // :441
     }
+    return ok;
+}
+
+// One step for one lane: the FAST path, then SAFE for the lanes that need it.
+// The outer test is wave-uniform (one scalar branch, normally not taken); the
+// inner one restricts the redo to the lanes that asked for it.
+template <typename T, bool K2, bool DIAG>
+__device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
+                                            const T tq[4], const T mu[4], T h, T *state_dot,
+                                            Outputs18<T> *outputs)
+{
+    T sn[10], axn, ayn;
+    const bool ok = rk4_step<T, K2, DIAG, false>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+    if (Math<T, false>::kHasRangeLimit) {
+        if (__builtin_expect(__any(!ok) != 0, 0)) {
+            if (!ok) rk4_step<T, K2, DIAG, true>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = sn[i];
+    ax = axn;
+    ay = ayn;
 }
 
 }  // namespace vdyn

@@ -17,11 +17,12 @@ namespace fm {
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }    // v_rsq_f32, 1 ulp
 
-// atan(x) for x >= 0, given inv_x = 1/x (the caller has it for free).
-// atan(t) = t P(t^2) on [0,1]; atan(x) = pi/2 - atan(1/x) above 1.
-__device__ __forceinline__ float atan_pos(float x, float inv_x)
+// atan(x), given inv_x = 1/x (the caller has it for free; x = B s >= 0 on this path,
+// but the sign is honoured).  atan(t) = t P(t^2) on [-1,1]; |x| > 1: atan(x) =
+// copysign(pi/2, x) - atan(1/x).
+__device__ __forceinline__ float atan_rcp(float x, float inv_x)
 {
-    const bool big = x > 1.0f;
+    const bool big = fabsf(x) > 1.0f;
     const float t = big ? inv_x : x;
     const float u = t * t;
     float p = 2.872858429e-03f;
@@ -33,7 +34,7 @@ __device__ __forceinline__ float atan_pos(float x, float inv_x)
     p = fmaf(p, u, 1.999291778e-01f);
     p = fmaf(p, u, -3.333308995e-01f);
     p = fmaf(p * u, t, t);  // t + t u P'(u): the leading coefficient is exactly 1
-    return big ? (1.57079637050628662109375f - p) : p;
+    return big ? (copysignf(1.57079637050628662109375f, x) - p) : p;
 }
 
 // sin(y) for |y| up to ~1e4: y = k pi + r, |r| <= pi/2, sin y = (-1)^k sin r.
@@ -52,28 +53,35 @@ __device__ __forceinline__ float sin_mid(float y)
     return __uint_as_float(__float_as_uint(s) ^ flip);
 }
 
-// sin and cos of an unbounded angle (yaw is never wrapped: quirk Q7).
-// Cody-Waite with three fused terms of pi/2 is exact enough while |x| <= 2^16;
-// beyond that the (never taken in practice) branch defers to the library.
-__device__ __forceinline__ void sincos_any(float x, float *sn, float *cs)
+// sin / cos kernels on |r| <= pi/4 (1 ulp)
+__device__ __forceinline__ void sincos_kernel(float r, float *sr, float *cr)
 {
-    if (__builtin_expect(!(fabsf(x) <= 65536.0f), 0)) {
-        ::sincosf(x, sn, cs);
-        return;
-    }
-    const float k = __builtin_rintf(x * 0.636619772367581343076f);
-    float r = fmaf(-k, 1.57079637050628662109375f, x);       // float(pi/2)
-    r = fmaf(-k, -4.37113900018624283e-08f, r);              // pi/2 - float(pi/2)
-    r = fmaf(-k, -1.7151245100059e-15f, r);
     const float u = r * r;
     float ps = -1.951163867e-04f;
     ps = fmaf(ps, u, 8.332134224e-03f);
     ps = fmaf(ps, u, -1.666665375e-01f);
-    const float sr = fmaf(r * u, ps, r);
+    *sr = fmaf(r * u, ps, r);
     float pc = 2.443367339e-05f;
     pc = fmaf(pc, u, -1.388732577e-03f);
     pc = fmaf(pc, u, 4.166664556e-02f);
-    const float cr = fmaf(u * u, pc, fmaf(-0.5f, u, 1.0f));
+    *cr = fmaf(u * u, pc, fmaf(-0.5f, u, 1.0f));
+}
+
+// Largest |x| for which sincos_mid's three-term Cody-Waite reduction holds 1-2 ulp.
+constexpr float kSincosMidLimit = 65536.0f;
+// Largest stage increment the kernels above cover without reduction.
+constexpr float kSincosKernelLimit = 0.78539816339f;
+
+// sin and cos for |x| <= kSincosMidLimit, straight-line (yaw is never wrapped by
+// the reference -- quirk Q7 -- so this has to take angles well beyond 2 pi).
+__device__ __forceinline__ void sincos_mid(float x, float *sn, float *cs)
+{
+    const float k = __builtin_rintf(x * 0.636619772367581343076f);
+    float r = fmaf(-k, 1.57079637050628662109375f, x);       // float(pi/2)
+    r = fmaf(-k, -4.37113900018624283e-08f, r);              // pi/2 - float(pi/2)
+    r = fmaf(-k, -1.7151245100059e-15f, r);
+    float sr, cr;
+    sincos_kernel(r, &sr, &cr);
     const int q = (int)k;
     const bool swap = (q & 1) != 0;
     const float s0 = swap ? cr : sr;

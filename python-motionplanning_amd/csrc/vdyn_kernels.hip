@@ -66,7 +66,6 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
 
     T sd[10];
     Outputs18<T> o18;
-    constexpr bool REAR = (K == 12);
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
@@ -88,7 +87,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
 
-            rk4_step<T, REAR, DIAG>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
+            rk4_advance<T, K == 2, DIAG>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
@@ -133,12 +132,14 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
     for (int i = 0; i < 10; ++i) s[i] = state[(int64_t)i * n + r];
     Ctrl<T, 12> c;
     c.set(P, ctrl12 + r, n);
+    // a single evaluation is latency-bound on the launch, not on math: full-range path
     StepInv<T> inv;
-    make_step_inv<T, true>(P, c.delta, c.tq, c.mu, acc_prev[r], acc_prev[n + r], inv);
+    bool ok = true;
+    make_step_inv<T, false, true>(P, c.delta, c.tq, c.mu, acc_prev[r], acc_prev[n + r], inv, ok);
     Outputs18<T> o;
     T sy, cy;
-    Math<T>::sincos(s[7], &sy, &cy);
-    planar_deriv<T, true, true>(P, inv, s, sy, cy, k, axc, ayc, &o);
+    Math<T, true>::sincos(s[7], &sy, &cy, ok);
+    planar_deriv<T, false, true, true>(P, inv, s, sy, cy, k, axc, ayc, &o);
 #pragma unroll
     for (int i = 0; i < 10; ++i) state_dot[(int64_t)i * n + r] = k[i];
     acc[r] = axc;
@@ -184,11 +185,11 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         for (int t = 0; t < H; ++t) {
             Ctrl<T, 2> cc;
             cc.set(P, cand + ((int64_t)t * 2) * C + c, C);
-            rk4_step<T, false, false>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h, nullptr, nullptr);
+            rk4_advance<T, true, false>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h, nullptr, nullptr);
             dsum += cc.delta[0] * cc.delta[0];
         }
         const T dx = s[8] - gx, dy = s[9] - gy;
-        const T cost = Math<T>::sqrt(dx * dx + dy * dy) + w_delta * dsum;
+        const T cost = sqrt_t(dx * dx + dy * dy) + w_delta * dsum;
         if (cost_all != nullptr) cost_all[(int64_t)e * C + c] = cost;
         if (cost < bc) { bc = cost; bi = c; }  // strict '<': lowest index wins ties; NaN/inf never win
     }
