@@ -81,10 +81,34 @@ template <> struct Math<float, true> {
     }
 };
 
-template <bool SAFE> struct Math<double, SAFE> {
+template <> struct Math<double, false> {
+    static constexpr bool kHasRangeLimit = true;
+    static __device__ __forceinline__ double rcp(double x) { return fm64::rcp(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return fm64::rsq(x); }
+    static __device__ __forceinline__ double sin_c_atan(double C, double x, double inv_x)
+    {
+        return fm64::sin_mid(C * fm64::atan_rcp(x, inv_x));
+    }
+    static __device__ __forceinline__ void sincos(double x, double *s, double *c, bool &ok)
+    {
+        fm64::sincos_mid(x, s, c);
+        ok = ok && (::fabs(x) <= fm64::kSincosMidLimit);
+    }
+    static __device__ __forceinline__ void stage_sincos(double sy0, double cy0, double, double d, double *s,
+                                                        double *c, bool &ok)
+    {
+        double sd, cd;
+        fm64::sincos_kernel(d, &sd, &cd);
+        *s = ::fma(sy0, cd, cy0 * sd);
+        *c = ::fma(cy0, cd, -sy0 * sd);
+        ok = ok && (::fabs(d) <= fm64::kSincosKernelLimit);
+    }
+};
+
+template <> struct Math<double, true> {
     static constexpr bool kHasRangeLimit = false;
-    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double rcp(double x) { return fm64::rcp(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return fm64::rsq(x); }
     static __device__ __forceinline__ double sin_c_atan(double C, double x, double) { return ::sin(C * ::atan(x)); }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c, bool &) { ::sincos(x, s, c); }
     static __device__ __forceinline__ void stage_sincos(double, double, double yaw, double, double *s, double *c,

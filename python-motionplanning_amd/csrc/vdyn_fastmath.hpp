@@ -93,4 +93,126 @@ __device__ __forceinline__ void sincos_mid(float x, float *sn, float *cs)
 }
 
 }  // namespace fm
+
+// ---- double precision: same structure, coefficients from tools/fit_polys_f64.py -------
+// (Chebyshev interpolants computed in 60-digit arithmetic, 1 ulp each.)  The hardware
+// v_rcp_f64 / v_rsq_f64 seeds are refined by two Newton steps instead of going through
+// the IEEE division / sqrt expansions (div_scale, div_fmas, div_fixup, ...).
+namespace fm64 {
+
+__device__ __forceinline__ double rcp(double a)
+{
+    double x = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-a, x, 1.0);
+    return fma(x, e, x);
+}
+
+__device__ __forceinline__ double rsq(double a)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    double e = fma(-a * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-a * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
+__device__ __forceinline__ double atan_rcp(double x, double inv_x)
+{
+    const bool big = fabs(x) > 1.0;
+    const double t = big ? inv_x : x;
+    const double u = t * t;
+    double p = 5.4235777122049743556e-6;
+    p = fma(p, u, -0.000068150143017768600815);
+    p = fma(p, u, 0.00040788678988090017583);
+    p = fma(p, u, -0.0015537533402612332627);
+    p = fma(p, u, 0.0042551148264804944648);
+    p = fma(p, u, -0.0089974339942772711199);
+    p = fma(p, u, 0.015464694610323185545);
+    p = fma(p, u, -0.022566714208211488805);
+    p = fma(p, u, 0.029121244608854832768);
+    p = fma(p, u, -0.034556867496289890707);
+    p = fma(p, u, 0.039051162476945009974);
+    p = fma(p, u, -0.043181268997216635355);
+    p = fma(p, u, 0.047543887590470330271);
+    p = fma(p, u, -0.052616416091309294506);
+    p = fma(p, u, 0.058821133510041307054);
+    p = fma(p, u, -0.066666376799540371802);
+    p = fma(p, u, 0.076923050864584886996);
+    p = fma(p, u, -0.090909089238135856884);
+    p = fma(p, u, 0.11111111103899985381);
+    p = fma(p, u, -0.14285714285522452249);
+    p = fma(p, u, 0.19999999999997281691);
+    p = fma(p, u, -0.33333333333333317957);
+    p = fma(p * u, t, t);
+    // pi/2 = hi + lo: the subtraction keeps the low word
+    return big ? ((copysign(1.570796326794896557998982, x) - p) + copysign(6.12323399573676603586882e-17, x)) : p;
+}
+
+// sin(y), |y| up to ~1e9: y = k pi + r, |r| <= pi/2
+__device__ __forceinline__ double sin_mid(double y)
+{
+    const double k = __builtin_rint(y * 0.3183098861837906715377675);
+    double r = fma(-k, 3.141592653589793115997963, y);
+    r = fma(-k, 1.224646799147353207173764e-16, r);
+    const double u = r * r;
+    double p = 1.9100730349358852685e-20;
+    p = fma(p, u, -8.2181658713046197275e-18);
+    p = fma(p, u, 2.8114500908387014114e-15);
+    p = fma(p, u, -7.6471636061405583964e-13);
+    p = fma(p, u, 1.6059043835456402796e-10);
+    p = fma(p, u, -2.5052108385432688701e-8);
+    p = fma(p, u, 2.7557319223985856341e-6);
+    p = fma(p, u, -0.00019841269841269841204);
+    p = fma(p, u, 0.0083333333333333333333);
+    p = fma(p, u, -0.16666666666666666667);
+    const double s = fma(r * u, p, r);
+    const unsigned long long flip = ((unsigned long long)(long long)k) << 63;
+    return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s) ^ flip));
+}
+
+__device__ __forceinline__ void sincos_kernel(double r, double *sr, double *cr)
+{
+    const double u = r * r;
+    double ps = -7.5865436341019028834e-13;
+    ps = fma(ps, u, 1.6058529011960856764e-10);
+    ps = fma(ps, u, -2.5052106215978872603e-8);
+    ps = fma(ps, u, 2.7557319219291695824e-6);
+    ps = fma(ps, u, -0.00019841269841265003859);
+    ps = fma(ps, u, 0.0083333333333333314638);
+    ps = fma(ps, u, -0.16666666666666666665);
+    *sr = fma(r * u, ps, r);
+    double pc = 4.7457865678652129218e-14;
+    pc = fma(pc, u, -1.1470459438155825967e-11);
+    pc = fma(pc, u, 2.0876755781924197192e-9);
+    pc = fma(pc, u, -2.7557319221376431924e-7);
+    pc = fma(pc, u, 0.000024801587301584612466);
+    pc = fma(pc, u, -0.001388888888888888785);
+    pc = fma(pc, u, 0.041666666666666666666);
+    *cr = fma(u * u, pc, fma(-0.5, u, 1.0));
+}
+
+constexpr double kSincosMidLimit = 1073741824.0;  // 2^30
+constexpr double kSincosKernelLimit = 0.78539816339744830962;
+
+__device__ __forceinline__ void sincos_mid(double x, double *sn, double *cs)
+{
+    const double k = __builtin_rint(x * 0.6366197723675813430755351);
+    double r = fma(-k, 1.570796326794896557998982, x);
+    r = fma(-k, 6.12323399573676603586882e-17, r);
+    r = fma(-k, -1.497384904859169832943508e-33, r);
+    double sr, cr;
+    sincos_kernel(r, &sr, &cr);
+    const long long q = (long long)k;
+    const bool swap = (q & 1) != 0;
+    const double s0 = swap ? cr : sr;
+    const double c0 = swap ? sr : cr;
+    const unsigned long long fs = ((unsigned long long)(q & 2)) << 62;
+    const unsigned long long fc = ((unsigned long long)((q + 1) & 2)) << 62;
+    *sn = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s0) ^ fs));
+    *cs = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(c0) ^ fc));
+}
+
+}  // namespace fm64
 }  // namespace vdyn
