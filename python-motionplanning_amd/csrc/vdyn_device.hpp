@@ -47,10 +47,13 @@ template <> struct Math<float, false> {
     static constexpr bool kHasRangeLimit = true;
     static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
-    // sin(C atan(x)), inv_x = 1/x
+    // sin(C atan(x)), inv_x = 1/x.  CS: the host guarantees 0 <= C <= 2 and B >= 0, so
+    // the argument of sin lies in [0, pi] and the reflection form applies.
+    template <bool CS>
     static __device__ __forceinline__ float sin_c_atan(float C, float x, float inv_x)
     {
-        return fm::sin_mid(C * fm::atan_rcp(x, inv_x));
+        const float y = C * fm::atan_rcp(x, inv_x);
+        return CS ? fm::sin_0_pi(y) : fm::sin_mid(y);
     }
     static __device__ __forceinline__ void sincos(float x, float *s, float *c, bool &ok)
     {
@@ -73,6 +76,7 @@ template <> struct Math<float, true> {
     static constexpr bool kHasRangeLimit = false;
     static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
+    template <bool CS>
     static __device__ __forceinline__ float sin_c_atan(float C, float x, float) { return ::sinf(C * ::atanf(x)); }
     static __device__ __forceinline__ void sincos(float x, float *s, float *c, bool &) { ::sincosf(x, s, c); }
     static __device__ __forceinline__ void stage_sincos(float, float, float yaw, float, float *s, float *c, bool &)
@@ -85,9 +89,11 @@ template <> struct Math<double, false> {
     static constexpr bool kHasRangeLimit = true;
     static __device__ __forceinline__ double rcp(double x) { return fm64::rcp(x); }
     static __device__ __forceinline__ double rsqrt(double x) { return fm64::rsq(x); }
+    template <bool CS>
     static __device__ __forceinline__ double sin_c_atan(double C, double x, double inv_x)
     {
-        return fm64::sin_mid(C * fm64::atan_rcp(x, inv_x));
+        const double y = C * fm64::atan_rcp(x, inv_x);
+        return CS ? fm64::sin_0_pi(y) : fm64::sin_mid(y);
     }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c, bool &ok)
     {
@@ -109,6 +115,7 @@ template <> struct Math<double, true> {
     static constexpr bool kHasRangeLimit = false;
     static __device__ __forceinline__ double rcp(double x) { return fm64::rcp(x); }
     static __device__ __forceinline__ double rsqrt(double x) { return fm64::rsq(x); }
+    template <bool CS>
     static __device__ __forceinline__ double sin_c_atan(double C, double x, double) { return ::sin(C * ::atan(x)); }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c, bool &) { ::sincos(x, s, c); }
     static __device__ __forceinline__ void stage_sincos(double, double, double yaw, double, double *s, double *c,
@@ -171,7 +178,7 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
 // (fxt, fyt), chassis-frame force (fx, fy) and combined slip s.
 //   :274-281 rotation, :284-293 slips (quirk Q4: signed vx for s_x, |vx| for s_y),
 //   :296-299 combined slip, :303-348 Pacejka + split, :351-373 forces.
-template <typename T, bool STEERED, bool SAFE>
+template <typename T, bool STEERED, bool SAFE, bool CS>
 __device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
                                            T &fx, T &fy, T &fxt, T &fyt, T &s_out)
 {
@@ -199,7 +206,7 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc,
     const T s2c = s2 > tiny_t(T(0)) ? s2 : tiny_t(T(0));
     const T rs = M::rsqrt(s2c);
     const T s = s2c * rs;
-    const T g = M::sin_c_atan(C, B * s, rs * invB) * rs;
+    const T g = M::template sin_c_atan<CS>(C, B * s, rs * invB) * rs;
     const T gf = g * muFz;
     fxt = sx * gf;
     fyt = sy * gf;
@@ -221,7 +228,7 @@ struct Outputs18 {
 
 // State derivative, vehicle_model.py:220-425.  s[10] = U,V,wz,wFL,wFR,wRL,wRR,yaw,x,y;
 // (sy, cy) = sin, cos of s[7].  Returns k[10] and the body accelerations axc, ayc (:413-414).
-template <typename T, bool K2, bool DIAG, bool SAFE>
+template <typename T, bool K2, bool DIAG, bool SAFE, bool CS>
 __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepInv<T> &c, const T s[10],
                                              T sy, T cy, T k[10], T &axc, T &ayc, Outputs18<T> *out)
 {
@@ -232,13 +239,13 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     const T vFy = V + P.a * wz, vRy = V - P.b * wz;
 
     T fx[4], fy[4], fxt[4], fyt[4], sl[4];
-    tire_force<T, true, SAFE>(P.B[0], P.invB[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
+    tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
                               fx[0], fy[0], fxt[0], fyt[0], sl[0]);
-    tire_force<T, true, SAFE>(P.B[1], P.invB[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
+    tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
                               fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-    tire_force<T, !K2, SAFE>(P.B[2], P.invB[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
+    tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
                              fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-    tire_force<T, !K2, SAFE>(P.B[3], P.invB[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
+    tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
                              fx[3], fy[3], fxt[3], fyt[3], sl[3]);
 
     // :376-385
@@ -275,7 +282,7 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
 // sn[10], (axn, ayn), the latter the 1-2-2-1 averages of axc, ayc (:442-443).
 // DIAG: also state_dot (:440) and the averaged outputs (:441).
 // Returns false for a lane that left the validated range of the FAST path.
-template <typename T, bool K2, bool DIAG, bool SAFE>
+template <typename T, bool K2, bool DIAG, bool SAFE, bool CS>
 __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T ax, T ay, const T delta[4],
                                          const T tq[4], const T mu[4], T h, T sn[10], T &axn, T &ayn,
                                          T *state_dot, Outputs18<T> *outputs)
@@ -293,14 +300,14 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
     T sy0, cy0, sy, cy;
     M::sincos(s[7], &sy0, &cy0, ok);
 
-    planar_deriv<T, K2, DIAG, SAFE>(P, c, s, sy0, cy0, k, a1, a2, &o);       // K1 (:429)
+    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, s, sy0, cy0, k, a1, a2, &o);       // K1 (:429)
     asx = a1; asy = a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = k[i]; st[i] = fma_t(hh, k[i], s[i]); }
     if (DIAG) osum = o;
 
     M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
-    planar_deriv<T, K2, DIAG, SAFE>(P, c, st, sy, cy, k, a1, a2, &o);        // K2 (:431)
+    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K2 (:431)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = fma_t(T(2), k[i], acc[i]); st[i] = fma_t(hh, k[i], s[i]); }
@@ -310,7 +317,7 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
     }
 
     M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
-    planar_deriv<T, K2, DIAG, SAFE>(P, c, st, sy, cy, k, a1, a2, &o);        // K3 (:433)
+    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K3 (:433)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = fma_t(T(2), k[i], acc[i]); st[i] = fma_t(h, k[i], s[i]); }
@@ -320,7 +327,7 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
     }
 
     M::stage_sincos(sy0, cy0, st[7], h * k[7], &sy, &cy, ok);
-    planar_deriv<T, K2, DIAG, SAFE>(P, c, st, sy, cy, k, a1, a2, &o);        // K4 (:435)
+    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K4 (:435)
     asx += a1; asy += a2;
     const T h6 = h * T(1.0 / 6.0), sixth = T(1.0 / 6.0);
 #pragma unroll
@@ -342,16 +349,16 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 // One step for one lane: the FAST path, then SAFE for the lanes that need it.
 // The outer test is wave-uniform (one scalar branch, normally not taken); the
 // inner one restricts the redo to the lanes that asked for it.
-template <typename T, bool K2, bool DIAG>
+template <typename T, bool K2, bool DIAG, bool CS>
 __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                             const T tq[4], const T mu[4], T h, T *state_dot,
                                             Outputs18<T> *outputs)
 {
     T sn[10], axn, ayn;
-    const bool ok = rk4_step<T, K2, DIAG, false>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+    const bool ok = rk4_step<T, K2, DIAG, false, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
     if (Math<T, false>::kHasRangeLimit) {
         if (__builtin_expect(__any(!ok) != 0, 0)) {
-            if (!ok) rk4_step<T, K2, DIAG, true>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+            if (!ok) rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
         }
     }
 #pragma unroll

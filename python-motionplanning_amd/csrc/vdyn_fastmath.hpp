@@ -53,6 +53,20 @@ __device__ __forceinline__ float sin_mid(float y)
     return __uint_as_float(__float_as_uint(s) ^ flip);
 }
 
+// sin(y) for y in [0, pi] (Pacejka shape factor 0 <= C <= 2: y = C atan(B s) <= pi):
+// reflect about pi/2 instead of the general reduction -- min + 2 adds replace
+// mul / rndne / 2 fma / cvt / shift / xor.
+__device__ __forceinline__ float sin_0_pi(float y)
+{
+    const float r = fminf(y, (3.1415927410125732421875f - y) + -8.74227800037248566e-08f);
+    const float u = r * r;
+    float p = 2.607052693e-06f;
+    p = fmaf(p, u, -1.981028618e-04f);
+    p = fmaf(p, u, 8.333077654e-03f);
+    p = fmaf(p, u, -1.666665971e-01f);
+    return fmaf(r * u, p, r);
+}
+
 // sin / cos kernels on |r| <= pi/4 (1 ulp)
 __device__ __forceinline__ void sincos_kernel(float r, float *sr, float *cr)
 {
@@ -170,6 +184,23 @@ __device__ __forceinline__ double sin_mid(double y)
     const double s = fma(r * u, p, r);
     const unsigned long long flip = ((unsigned long long)(long long)k) << 63;
     return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s) ^ flip));
+}
+
+__device__ __forceinline__ double sin_0_pi(double y)
+{
+    const double r = fmin(y, (3.141592653589793115997963 - y) + 1.224646799147353207173764e-16);
+    const double u = r * r;
+    double p = 1.9100730349358852685e-20;
+    p = fma(p, u, -8.2181658713046197275e-18);
+    p = fma(p, u, 2.8114500908387014114e-15);
+    p = fma(p, u, -7.6471636061405583964e-13);
+    p = fma(p, u, 1.6059043835456402796e-10);
+    p = fma(p, u, -2.5052108385432688701e-8);
+    p = fma(p, u, 2.7557319223985856341e-6);
+    p = fma(p, u, -0.00019841269841269841204);
+    p = fma(p, u, 0.0083333333333333333333);
+    p = fma(p, u, -0.16666666666666666667);
+    return fma(r * u, p, r);
 }
 
 __device__ __forceinline__ void sincos_kernel(double r, double *sr, double *cr)

@@ -41,7 +41,9 @@ struct Ctrl {
 // H zero-order-hold RK4 steps per lane (the loop of drive.py:114,141-143 with
 // vehicle_model.py:427-445 inside).  DIAG additionally returns the last step's
 // state_dot / outputs (used for H = 1: the planar_model_RK4 drop-in).
-template <typename T, int K, int LAYOUT, bool DIAG>
+// CS: Pacejka shape factors in [0, 2] and B >= 0 (true of any realistic tire, and of the
+// reference's 1.5047): sin's argument stays in [0, pi] and takes the short reflection form.
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS>
 __global__ void __launch_bounds__(kBlock)
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
@@ -87,7 +89,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
 
-            rk4_advance<T, K == 2, DIAG>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
+            rk4_advance<T, K == 2, DIAG, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
@@ -139,7 +141,7 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
     Outputs18<T> o;
     T sy, cy;
     Math<T, true>::sincos(s[7], &sy, &cy, ok);
-    planar_deriv<T, false, true, true>(P, inv, s, sy, cy, k, axc, ayc, &o);
+    planar_deriv<T, false, true, true, false>(P, inv, s, sy, cy, k, axc, ayc, &o);
 #pragma unroll
     for (int i = 0; i < 10; ++i) state_dot[(int64_t)i * n + r] = k[i];
     acc[r] = axc;
@@ -158,7 +160,7 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
 
 // Config-5 MPC selection.  Block = one ego; lanes stride over the C shared
 // candidates; cost and (min, argmin) never leave the chip until the final pair.
-template <typename T>
+template <typename T, bool CS>
 __global__ void __launch_bounds__(1024)
 mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego,
                   const T *__restrict__ cand, const T *__restrict__ goal, T h, T w_delta,
@@ -185,7 +187,7 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         for (int t = 0; t < H; ++t) {
             Ctrl<T, 2> cc;
             cc.set(P, cand + ((int64_t)t * 2) * C + c, C);
-            rk4_advance<T, true, false>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h, nullptr, nullptr);
+            rk4_advance<T, true, false, CS>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h, nullptr, nullptr);
             dsum += cc.delta[0] * cc.delta[0];
         }
         const T dx = s[8] - gx, dy = s[9] - gy;
@@ -243,7 +245,14 @@ DevParams<T> make_dev_params(const VdynParams &p, const double *mu4)
     return d;
 }
 
-template <typename T, int K, int LAYOUT, bool DIAG>
+static bool shape_factors_small(const VdynParams &p)
+{
+    for (int i = 0; i < 4; ++i)
+        if (!(p.C[i] >= 0.0 && p.C[i] <= 2.0 && p.B[i] >= 0.0)) return false;
+    return true;
+}
+
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS>
 static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
 {
     const DevParams<T> P = make_dev_params<T>(p, a.mu4);
@@ -255,7 +264,7 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
         chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
         lds = (size_t)chunk * per_step;
     }
-    hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+    hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
                        a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
                        a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
     return hipGetLastError();
@@ -268,10 +277,13 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     int layout = a.layout;
     if (layout == VDYN_CTRL_SHARED && (size_t)a.P * a.k * sizeof(T) > (size_t)kLdsBudget) layout = 2;
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
+    const bool cs = shape_factors_small(p);
+    // the diagnostic (single-step drop-in) variants are launch-latency bound: general form only
 #define VDYN_DISPATCH(KK, LL)                                                          \
     if (a.k == KK && layout == LL)                                                     \
-        return diag ? launch_rollout_impl<T, KK, LL, true>(p, a, st)                   \
-                    : launch_rollout_impl<T, KK, LL, false>(p, a, st);
+        return diag ? launch_rollout_impl<T, KK, LL, true, false>(p, a, st)            \
+               : cs ? launch_rollout_impl<T, KK, LL, false, true>(p, a, st)            \
+                    : launch_rollout_impl<T, KK, LL, false, false>(p, a, st);
     VDYN_DISPATCH(2, 0)
     VDYN_DISPATCH(2, 1)
     VDYN_DISPATCH(2, 2)
@@ -304,8 +316,12 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
     int block = ((C + 63) / 64) * 64;
     block = std::max(64, std::min(block, 1024));
-    hipLaunchKernelGGL((mpc_argmin_kernel<T>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E, C,
-                       H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+    if (shape_factors_small(p))
+        hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
+                           C, H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+    else
+        hipLaunchKernelGGL((mpc_argmin_kernel<T, false>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
+                           C, H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
     return hipGetLastError();
 }
 
