@@ -24,6 +24,8 @@ int oracle_max_threads(void)
 #define ATAN atan
 #define SQRT sqrt
 #define FABS fabs
+#define ATAN2 atan2
+#define FMOD fmod
 #include "vdyn_oracle_body.inc"
 #undef REAL
 #undef X
@@ -32,6 +34,8 @@ int oracle_max_threads(void)
 #undef ATAN
 #undef SQRT
 #undef FABS
+#undef ATAN2
+#undef FMOD
 
 #define REAL float
 #define X(name) name##_f32
@@ -40,4 +44,6 @@ int oracle_max_threads(void)
 #define ATAN atanf
 #define SQRT sqrtf
 #define FABS fabsf
+#define ATAN2 atan2f
+#define FMOD fmodf
 #include "vdyn_oracle_body.inc"

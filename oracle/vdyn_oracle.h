@@ -25,6 +25,12 @@ typedef struct OracleParams {
     double B[4], C[4]; /* FL, FR, RL, RR */
 } OracleParams;
 
+/* Gains of the two controllers (stanley_controller.py:40-47,140-143; values at drive.py:71-85). */
+typedef struct OracleCtrlParams {
+    double k, k_soft, max_steer, lookahead, deadband; /* Stanley */
+    double kp, ki, kd;                                /* longitudinal PID */
+} OracleCtrlParams;
+
 #define ORACLE_DECL(S, REAL)                                                                   \
     void oracle_planar_model_##S(const OracleParams *p, const REAL *state,                     \
                                  const REAL *tire_torques, const REAL *mu_max,                 \
@@ -39,6 +45,15 @@ typedef struct OracleParams {
                            const REAL *state0, const REAL *ctrl, int k, int layout,            \
                            const int *path_id, int P, const double *mu4, REAL *terminal,       \
                            REAL *traj, int traj_stride, int nthreads);                         \
+    void oracle_stanley_control_##S(const OracleCtrlParams *g, const REAL *wp, int W, int stride,       \
+                                    REAL x, REAL y, REAL yaw, REAL v, REAL *out);                       \
+    void oracle_long_control_##S(const OracleCtrlParams *g, REAL desired, REAL current, REAL prev,      \
+                                 REAL total, REAL dt, REAL *out);                                       \
+    int oracle_closed_loop_##S(const OracleParams *p, const OracleCtrlParams *g, long n, int H,         \
+                               double dt, int ctrl_every, int phase, const REAL *state0,                \
+                               const REAL *cstate0, const REAL *wp, int Wmax, const int *wcount,        \
+                               const int *path_id, int P, REAL *terminal, REAL *cstate, REAL *log,      \
+                               int nthreads);                                                           \
     int oracle_mpc_argmin_##S(const OracleParams *p, int E, int C, int H, double dt,           \
                               const REAL *ego, const REAL *cand, const REAL *goal,             \
                               REAL w_delta, REAL *best_cost, int *best_idx, REAL *cost_all,    \

@@ -21,6 +21,10 @@ Sets:
   G6 the reference fed float32 arrays on the G3 inputs (fp32 floor, informational)
   G7 config-5 shaped MPC case (4 egos x 16 candidates x 50 steps)
   G8 config-3 shaped case (16 egos x 7 lattice paths x 200 steps)
+  G9 closed-loop controller logs of the same 3-frame Car.drive run as G4 (world.path):
+     the waypoint lists the planner handed to the Stanley controller, every
+     stanley_control / long_control call (inputs -> outputs) and the steering filter
+     state (drive.py:128-138, stanley_controller.py:56-159)
 """
 import importlib
 import os
@@ -284,7 +288,69 @@ def g8():
     print("G8", np.array(term).shape)
 
 
+def g9():
+    import scipy.integrate
+    if not hasattr(scipy.integrate, "cumtrapz"):
+        scipy.integrate.cumtrapz = scipy.integrate.cumulative_trapezoid
+    import libs.vehicle_model.drive as drive
+    from libs.utils.env import world
+    drive.os.system = lambda *_a, **_k: 0
+    path = world.path
+    frames = 3
+    car = drive.Car(path.px[10], path.py[10], path.pyaw[10], path.px, path.py, path.pyaw,
+                    0.01 / drive.Veh_SIM_NUM)
+    init = dict(state=np.array(car.state, dtype=np.float64), ax_ay_prev=np.array([car.ax_prev, car.ay_prev], float),
+                x_del=np.float64(car.x_del[-1]), total_vel_error=np.float64(car.total_vel_error),
+                prev_vel=np.float64(car.prev_vel), target_vel=np.float64(car.target_vel))
+    wps, st_in, st_out, st_wp, pid_in, pid_out, rk = [], [], [], [], [], [], []
+    lt, lg, kb = car.lateral_tracker, car.long_tracker, car.kbm
+    upd, sc, lc, rk4 = lt.update_waypoints, lt.stanley_control, lg.long_control, kb.planar_model_RK4
+
+    def spy_upd(new_wp):
+        wps.append(np.array(new_wp, dtype=np.float64))
+        return upd(new_wp)
+
+    def spy_sc(x, y, yaw, v):
+        o = sc(x, y, yaw, v)
+        st_in.append([x, y, yaw, v]); st_out.append([o[0], o[1], o[2]]); st_wp.append(len(wps) - 1)
+        return o
+
+    def spy_lc(des, cur, prev, tot, dt):
+        o = lc(des, cur, prev, tot, dt)
+        pid_in.append([des, cur, prev, tot, dt]); pid_out.append([o[0], o[1][0]])
+        assert o[1][0] == o[1][1] == o[1][2] == o[1][3]
+        return o
+
+    def spy_rk(state, tq, mu, delta, p, axp, ayp):
+        o = rk4(state, tq, mu, delta, p, axp, ayp)
+        rk.append(np.concatenate([o[0], [o[7], o[8]], [delta[0], tq[0]]]))
+        return o
+
+    lt.update_waypoints, lt.stanley_control, lg.long_control, kb.planar_model_RK4 = spy_upd, spy_sc, spy_lc, spy_rk
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for fr in range(frames):
+            car.drive(fr)
+    rk = np.array(rk)
+    g4 = np.load(os.path.join(HERE, "g4_closed_loop_world.npz"))
+    assert np.array_equal(rk[:, :10], g4["state_update"]), "G9 must come from the same trajectory as G4"
+    nmax = max(len(w) for w in wps)
+    wp_pad = np.full((len(wps), nmax, 3), np.nan)
+    for i, w in enumerate(wps):
+        wp_pad[i, :len(w)] = w
+    np.savez_compressed(
+        os.path.join(HERE, "g9_closed_loop_controls.npz"), waypoints=wp_pad,
+        waypoint_count=np.array([len(w) for w in wps], dtype=np.int32),
+        stanley_in=np.array(st_in), stanley_out=np.array(st_out, dtype=np.float64),
+        stanley_wp=np.array(st_wp, dtype=np.int32), pid_in=np.array(pid_in), pid_out=np.array(pid_out),
+        rk4_log=rk, x_del_log=np.array(car.x_del, dtype=np.float64), dt=np.float64(kb.dt),
+        gains=np.array([lt.k, lt.k_soft, lt.max_steer, lt._lookahead_distance, lt.cross_track_deadband,
+                        lg.kp, lg.ki, lg.kd]), **init)
+    print("G9 waypoints", [len(w) for w in wps], "stanley calls", len(st_in),
+          "idx range", int(np.min(np.array(st_out)[:, 1])), int(np.max(np.array(st_out)[:, 1])))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

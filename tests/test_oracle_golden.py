@@ -179,3 +179,44 @@ def test_empty_and_bad_inputs(oracle):
         oracle.rollout(p, np.zeros((12, 3)), np.zeros((5, 3, 3)), 1e-3)
     with pytest.raises(ValueError):
         oracle.rollout(p, np.zeros((12, 3)), np.zeros((2, 5, 2)), 1e-3, path_id=[0, 1, 2])
+
+
+# ---- "next" row 1: controllers (G9) -------------------------------------------------------
+def test_g9_stanley_and_pid_calls(oracle):
+    """Every stanley_control / long_control call of 3 frames of the reference's Car.drive."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    gains = g["gains"]
+    cp = oracle.ctrl_params(k=gains[0], k_soft=gains[1], max_steer=gains[2], lookahead=gains[3],
+                            deadband=gains[4], kp=gains[5], ki=gains[6], kd=gains[7])
+    for i in range(len(g["stanley_in"])):
+        f = int(g["stanley_wp"][i])
+        wp = g["waypoints"][f, :g["waypoint_count"][f]]
+        d, idx, cte = oracle.stanley_control(cp, wp, *g["stanley_in"][i])
+        assert idx == int(g["stanley_out"][i, 1])
+        assert abs(d - g["stanley_out"][i, 0]) <= 1e-12 and abs(cte - g["stanley_out"][i, 2]) <= 1e-12
+        tot, tau = oracle.long_control(cp, *g["pid_in"][i])
+        assert abs(tot - g["pid_out"][i, 0]) <= 1e-15 and abs(tau - g["pid_out"][i, 1]) <= 1e-11
+
+
+def test_g9_closed_loop_three_frames(oracle):
+    """The whole closed loop (controllers + filter + RK4) frame by frame with the planner's
+    waypoint lists as inputs reproduces the reference's 300-step trajectory (G4/G9)."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    gains = g["gains"]
+    cp = oracle.ctrl_params(k=gains[0], k_soft=gains[1], max_steer=gains[2], lookahead=gains[3],
+                            deadband=gains[4], kp=gains[5], ki=gains[6], kd=gains[7])
+    p = oracle.default_params()
+    dt = float(g["dt"])
+    s = np.concatenate([g["state"], g["ax_ay_prev"]])[:, None]
+    c = np.array([g["x_del"], g["total_vel_error"], g["prev_vel"], g["target_vel"], 0.0, 0.0])[:, None]
+    for f in range(3):
+        wp = g["waypoints"][f:f + 1, :, :2].copy()
+        wp[np.isnan(wp)] = 0.0
+        s, c, log = oracle.closed_loop(p, cp, s, c, wp, g["waypoint_count"][f:f + 1], [0], dt, 100, log=True)
+        want = g["rk4_log"][f * 100:(f + 1) * 100]                      # state12, delta, torque
+        close(log[:, :12, 0], want[:, :12], 1e-10)
+        close(log[:, 12, 0], want[:, 12], 1e-11)
+        close(log[:, 13, 0], want[:, 13], 1e-9)
+        idx = g["stanley_out"][f * 10:(f + 1) * 10, 1]
+        assert np.array_equal(log[::10, 14, 0], idx)
+    assert abs(c[0, 0] - g["x_del_log"][-1]) <= 1e-14
