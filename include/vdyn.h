@@ -67,6 +67,15 @@ typedef struct VdynParams {
     double B[4], C[4]; /* Pacejka B, C for FL, FR, RL, RR (vehicle_model.py:41-54) */
 } VdynParams;
 
+/* Replaces: the gains StanleyController.__init__ / LongitudinalController.__init__ take
+ * (stanley_controller.py:8-10,40-47,139-143; values used: drive.py:56,71-85) and the
+ * steering-filter constant 1e-5 / (2 * 0.001) of drive.py:137. */
+typedef struct VdynCtrlGains {
+    double k, k_soft, max_steer, lookahead, deadband; /* Stanley */
+    double kp, ki, kd;                                /* longitudinal PID */
+    double filter_gain;                               /* x_del <- (1 - g) x_del + g delta */
+} VdynCtrlGains;
+
 typedef struct VdynHandle VdynHandle;
 
 int vdyn_abi_version(void);
@@ -162,6 +171,64 @@ int vdyn_mpc_argmin_f32_host(VdynHandle *h, int32_t E, int32_t C, int32_t H, con
 int vdyn_mpc_argmin_f64_host(VdynHandle *h, int32_t E, int32_t C, int32_t H, const double *ego,
                              const double *cand, const double *goal, double dt, double w_delta,
                              double *best_cost, int32_t *best_idx, double *cost_all);
+
+/* ==== "next" row: the controllers either side of the path ================================
+ * cstate [6][n] rows: x_del (steering-filter state, drive.py:77,137), total_vel_error and
+ * prev_vel (PID memory, drive.py:50,52,131-134), target_vel (drive.py:51), delta and torque
+ * (the held commands, drive.py:138,131).  Waypoints: wp [P][Wmax][2] = (x, y) rows of the
+ * lists LateralTrackerObj.update_waypoints receives (local_planner.py:419), wcount [P] valid
+ * rows per table, path_id [n] the table each vehicle tracks.                                 */
+
+/* Gains of Car.__init__ (drive.py:56,71-85): k=100, k_soft=1, max_steer=30 deg, lookahead=5,
+ * deadband=0.01 (stanley_controller.py:46-47), kp=1000, ki=100, kd=0, filter 1e-5/(2*0.001). */
+void vdyn_ctrl_gains_default(VdynCtrlGains *g);
+
+/* ---- one controller update for n vehicles -------------------------------------------------
+ * Replaces: StanleyController.stanley_control (stanley_controller.py:78-129, incl.
+ * get_lookahead_index :56-76), LongitudinalController.long_control (:138-159) and the filter
+ * of drive.py:137-138, i.e. the `i % 10 == 0` block of drive.py:128-138.
+ * state12 [12][n] (rows x, y, yaw, U are read), cstate_in [6][n]
+ * -> cstate_out [6][n] (may alias cstate_in), out [3][n] = limited Stanley steering angle
+ *    (before the filter), target index, crosstrack error (stanley_controller.py:129).        */
+int vdyn_controller_update_f64_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, const double *state12,
+                                   const double *cstate_in, const double *wp, int32_t Wmax,
+                                   const int32_t *wcount, const int32_t *path_id, int32_t P, double dt,
+                                   double *cstate_out, double *out, void *stream);
+int vdyn_controller_update_f32_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, const float *state12,
+                                   const float *cstate_in, const float *wp, int32_t Wmax,
+                                   const int32_t *wcount, const int32_t *path_id, int32_t P, double dt,
+                                   float *cstate_out, float *out, void *stream);
+int vdyn_controller_update_f64_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, const double *state12,
+                                    const double *cstate_in, const double *wp, int32_t Wmax,
+                                    const int32_t *wcount, const int32_t *path_id, int32_t P, double dt,
+                                    double *cstate_out, double *out);
+int vdyn_controller_update_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, const float *state12,
+                                    const float *cstate_in, const float *wp, int32_t Wmax,
+                                    const int32_t *wcount, const int32_t *path_id, int32_t P, double dt,
+                                    float *cstate_out, float *out);
+
+/* ---- closed-loop rollout: H sub-steps of Car.drive (drive.py:114-151) minus the planner -----
+ * Controllers fire when (phase + t) % ctrl_every == 0 (drive.py:128: ctrl_every = 10) and hold
+ * their commands in between; every sub-step is the RK4 step of vdyn_step_* with
+ * delta=[d,d,0,0], torques=[t,t,t,t], mu_max=[1,1,1,1] (drive.py:141-143).
+ * -> terminal [12][n], cstate_out [6][n], log (nullable) [H][16][n] with rows state12, delta,
+ *    torque, target index, crosstrack error: the per-step content of drive.py:145-151.       */
+int vdyn_closed_loop_f64_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
+                             int32_t phase, const double *state0, const double *cstate_in, const double *wp,
+                             int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
+                             double dt, double *terminal, double *cstate_out, double *log, void *stream);
+int vdyn_closed_loop_f32_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
+                             int32_t phase, const float *state0, const float *cstate_in, const float *wp,
+                             int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
+                             double dt, float *terminal, float *cstate_out, float *log, void *stream);
+int vdyn_closed_loop_f64_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
+                              int32_t phase, const double *state0, const double *cstate_in, const double *wp,
+                              int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
+                              double dt, double *terminal, double *cstate_out, double *log);
+int vdyn_closed_loop_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
+                              int32_t phase, const float *state0, const float *cstate_in, const float *wp,
+                              int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
+                              double dt, float *terminal, float *cstate_out, float *log);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,8 @@ module) or with ``importlib.import_module("python-motionplanning_amd")``.
 """
 from . import workloads  # noqa: F401  (pure NumPy, needs no GPU)
 
-__all__ = ["workloads", "VehicleModel", "VehicleParameters", "VdynError"]
+__all__ = ["workloads", "VehicleModel", "VehicleParameters", "VdynError", "StanleyController",
+           "LongitudinalController"]
 
 
 def __getattr__(name):
@@ -22,6 +23,10 @@ def __getattr__(name):
         import importlib
         mod = importlib.import_module(__name__ + ".vehicle_model")
         return mod if name == "vehicle_model" else getattr(mod, name)
+    if name in ("StanleyController", "LongitudinalController", "controllers"):
+        import importlib
+        mod = importlib.import_module(__name__ + ".controllers")
+        return mod if name == "controllers" else getattr(mod, name)
     if name in ("distributed", "_lib", "_build"):
         import importlib
         return importlib.import_module(__name__ + "." + name)

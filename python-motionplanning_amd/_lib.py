@@ -32,6 +32,12 @@ class VdynParams(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_[:11]) + tuple(self.B) + tuple(self.C)
 
 
+class VdynCtrlGains(C.Structure):
+    """Mirror of ``struct VdynCtrlGains`` (include/vdyn.h)."""
+    _fields_ = [(n, C.c_double) for n in
+                ("k", "k_soft", "max_steer", "lookahead", "deadband", "kp", "ki", "kd", "filter_gain")]
+
+
 _vp = C.c_void_p
 _i32, _i64, _dbl, _int = C.c_int32, C.c_int64, C.c_double, C.c_int
 
@@ -45,6 +51,7 @@ SIGNATURES = {
     "vdyn_destroy": (None, [_vp]),
     "vdyn_last_error": (C.c_char_p, [_vp]),
     "vdyn_stream_synchronize": (_int, [_vp, _vp]),
+    "vdyn_ctrl_gains_default": (None, [C.POINTER(VdynCtrlGains)]),
 }
 for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_planar_model_{_s}_dev"] = (_int, [_vp, _i64] + [_vp] * 7 + [_vp])
@@ -59,6 +66,15 @@ for _s in ("f32", "f64"):
                                                       _vp, _vp, _vp, _vp])
     SIGNATURES[f"vdyn_mpc_argmin_{_s}_host"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _dbl, _dbl,
                                                        _vp, _vp, _vp])
+
+_gp = C.POINTER(VdynCtrlGains)
+for _s in ("f32", "f64"):
+    _cu = [_vp, _gp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp]
+    SIGNATURES[f"vdyn_controller_update_{_s}_dev"] = (_int, _cu + [_vp])
+    SIGNATURES[f"vdyn_controller_update_{_s}_host"] = (_int, _cu)
+    _cl = [_vp, _gp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp, _vp]
+    SIGNATURES[f"vdyn_closed_loop_{_s}_dev"] = (_int, _cl + [_vp])
+    SIGNATURES[f"vdyn_closed_loop_{_s}_host"] = (_int, _cl)
 
 _lib = None
 
@@ -97,6 +113,12 @@ def default_params():
     p = VdynParams()
     load().vdyn_params_default(C.byref(p))
     return p
+
+
+def default_ctrl_gains():
+    g = VdynCtrlGains()
+    load().vdyn_ctrl_gains_default(C.byref(g))
+    return g
 
 
 class Handle:

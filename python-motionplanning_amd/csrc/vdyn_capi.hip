@@ -86,6 +86,20 @@ void vdyn_params_default(VdynParams *p)
     }
 }
 
+void vdyn_ctrl_gains_default(VdynCtrlGains *g)
+{
+    if (!g) return;
+    g->k = 100.0;                                     // drive.py:71
+    g->k_soft = 1.0;                                  // drive.py:72
+    g->max_steer = 30.0 * 3.141592653589793 / 180.0;  // drive.py:56 np.deg2rad(30)
+    g->lookahead = 5.0;                               // stanley_controller.py:46
+    g->deadband = 0.01;                               // stanley_controller.py:47
+    g->kp = 1000.0;                                   // drive.py:83
+    g->ki = 100.0;                                    // drive.py:84
+    g->kd = 0.0;                                      // drive.py:85
+    g->filter_gain = 1e-5 / (2 * 0.001);              // drive.py:137
+}
+
 int vdyn_create(const VdynParams *p, int device, VdynHandle **out)
 {
     if (!p || !out) { g_create_error = "vdyn_create: null argument"; return VDYN_ERR_ARG; }
@@ -354,6 +368,80 @@ int mpc_host(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, co
 }
 
 template <typename T>
+int closed_loop_check(VdynHandle *h, const VdynCtrlGains *g, const vdyn::ClosedLoopArgs<T> &a, bool update_only,
+                      const char *who)
+{
+    const std::string w(who);
+    if (!g) return h->fail(VDYN_ERR_ARG, w + ": null gains");
+    if (a.n < 0 || a.H < 0) return h->fail(VDYN_ERR_ARG, w + ": n < 0 or H < 0");
+    if (a.ctrl_every <= 0 || a.phase < 0) return h->fail(VDYN_ERR_ARG, w + ": need ctrl_every > 0, phase >= 0");
+    if (a.P <= 0 || a.Wmax <= 0) return h->fail(VDYN_ERR_ARG, w + ": need P > 0 and Wmax > 0");
+    if (!std::isfinite(a.dt)) return h->fail(VDYN_ERR_ARG, w + ": dt is not finite");
+    if (a.n == 0) return VDYN_OK;
+    if (!a.state0 || !a.cstate0 || !a.wp || !a.wcount || !a.path_id || !a.cstate)
+        return h->fail(VDYN_ERR_ARG, w + ": null buffer");
+    if (update_only ? !a.ctrl_out : !a.terminal) return h->fail(VDYN_ERR_ARG, w + ": null output buffer");
+    return VDYN_OK;
+}
+
+template <typename T>
+int closed_loop_dev(VdynHandle *h, const VdynCtrlGains *g, const vdyn::ClosedLoopArgs<T> &a, bool update_only,
+                    void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    const char *who = update_only ? "controller_update" : "closed_loop";
+    int rc = closed_loop_check<T>(h, g, a, update_only, who);
+    if (rc || a.n == 0) return rc;
+    VDYN_HIP(h, hipSetDevice(h->device));
+    if (update_only) VDYN_HIP(h, vdyn::launch_controller_update<T>(*g, a, (hipStream_t)stream));
+    else VDYN_HIP(h, vdyn::launch_closed_loop<T>(h->p, *g, a, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int closed_loop_host(VdynHandle *h, const VdynCtrlGains *g, vdyn::ClosedLoopArgs<T> a, bool update_only)
+{
+    if (!h) return VDYN_ERR_ARG;
+    const char *who = update_only ? "controller_update" : "closed_loop";
+    int rc = closed_loop_check<T>(h, g, a, update_only, who);
+    if (rc || a.n == 0) return rc;
+    const size_t e = sizeof(T) * (size_t)a.n;
+    Stage s(h);
+    const size_t i0 = s.in(a.state0, 12 * e), i1 = s.in(a.cstate0, 6 * e),
+                 i2 = s.in(a.wp, sizeof(T) * (size_t)a.P * a.Wmax * 2),
+                 i3 = s.in(a.wcount, sizeof(int32_t) * (size_t)a.P), i4 = s.in(a.path_id, sizeof(int32_t) * (size_t)a.n);
+    const size_t o0 = s.out(a.terminal, 12 * e), o1 = s.out(a.cstate, 6 * e),
+                 o2 = s.out(a.log, a.log ? (size_t)a.H * 16 * e : 0), o3 = s.out(a.ctrl_out, 3 * e);
+    rc = s.upload();
+    if (rc) return rc;
+    a.state0 = s.dev<T>(i0, false);
+    a.cstate0 = s.dev<T>(i1, false);
+    a.wp = s.dev<T>(i2, false);
+    a.wcount = s.dev<int>(i3, false);
+    a.path_id = s.dev<int>(i4, false);
+    a.terminal = s.dev<T>(o0, true);
+    a.cstate = s.dev<T>(o1, true);
+    a.log = s.dev<T>(o2, true);
+    a.ctrl_out = s.dev<T>(o3, true);
+    rc = closed_loop_dev<T>(h, g, a, update_only, h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+vdyn::ClosedLoopArgs<T> cl_args(int64_t n, int32_t H, int32_t ctrl_every, int32_t phase, const T *state0,
+                                const T *cstate_in, const T *wp, int32_t Wmax, const int32_t *wcount,
+                                const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log,
+                                T *ctrl_out)
+{
+    vdyn::ClosedLoopArgs<T> a;
+    a.n = n; a.H = H; a.ctrl_every = ctrl_every; a.phase = phase; a.state0 = state0; a.cstate0 = cstate_in;
+    a.wp = wp; a.Wmax = Wmax; a.wcount = wcount; a.path_id = path_id; a.P = P; a.dt = dt;
+    a.terminal = terminal; a.cstate = cstate_out; a.log = log; a.ctrl_out = ctrl_out;
+    return a;
+}
+
+template <typename T>
 vdyn::RolloutArgs<T> step_args(int64_t n, const T *state_in, const T *ctrl, int k, double dt,
                                const double *mu4, T *state_out, T *state_dot, T *outputs)
 {
@@ -435,5 +523,43 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
         return mpc_host<T>(h, E, C, H, ego, cand, goal, dt, w_delta, best_cost, best_idx, cost_all);     \
     }
 
+#define VDYN_DEFINE_CTRL_ABI(S, T)                                                                       \
+    extern "C" int vdyn_controller_update_##S##_dev(                                                     \
+        VdynHandle *h, const VdynCtrlGains *g, int64_t n, const T *state12, const T *cstate_in, const T *wp, \
+        int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P, double dt, T *cstate_out, \
+        T *out, void *stream)                                                                            \
+    {                                                                                                    \
+        return closed_loop_dev<T>(h, g, cl_args<T>(n, 0, 1, 0, state12, cstate_in, wp, Wmax, wcount, path_id, \
+                                                   P, dt, nullptr, cstate_out, nullptr, out), true, stream); \
+    }                                                                                                    \
+    extern "C" int vdyn_controller_update_##S##_host(                                                    \
+        VdynHandle *h, const VdynCtrlGains *g, int64_t n, const T *state12, const T *cstate_in, const T *wp, \
+        int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P, double dt, T *cstate_out, \
+        T *out)                                                                                          \
+    {                                                                                                    \
+        return closed_loop_host<T>(h, g, cl_args<T>(n, 0, 1, 0, state12, cstate_in, wp, Wmax, wcount, path_id, \
+                                                    P, dt, nullptr, cstate_out, nullptr, out), true);    \
+    }                                                                                                    \
+    extern "C" int vdyn_closed_loop_##S##_dev(                                                           \
+        VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every, int32_t phase,  \
+        const T *state0, const T *cstate_in, const T *wp, int32_t Wmax, const int32_t *wcount,           \
+        const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log, void *stream)  \
+    {                                                                                                    \
+        return closed_loop_dev<T>(h, g, cl_args<T>(n, H, ctrl_every, phase, state0, cstate_in, wp, Wmax, wcount, \
+                                                   path_id, P, dt, terminal, cstate_out, log, nullptr),  \
+                                  false, stream);                                                        \
+    }                                                                                                    \
+    extern "C" int vdyn_closed_loop_##S##_host(                                                          \
+        VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every, int32_t phase,  \
+        const T *state0, const T *cstate_in, const T *wp, int32_t Wmax, const int32_t *wcount,           \
+        const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log)                \
+    {                                                                                                    \
+        return closed_loop_host<T>(h, g, cl_args<T>(n, H, ctrl_every, phase, state0, cstate_in, wp, Wmax, wcount, \
+                                                    path_id, P, dt, terminal, cstate_out, log, nullptr), \
+                                   false);                                                               \
+    }
+
 VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
+VDYN_DEFINE_CTRL_ABI(f32, float)
+VDYN_DEFINE_CTRL_ABI(f64, double)

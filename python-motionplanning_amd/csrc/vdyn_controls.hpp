@@ -1,0 +1,173 @@
+// vdyn_controls.hpp -- the controllers either side of the RK4 path, per lane, for gfx950.
+//
+// Semantics:
+//   /root/reference/libs/controllers/stanley_controller.py:56-76    get_lookahead_index
+//   /root/reference/libs/controllers/stanley_controller.py:78-129   stanley_control
+//   /root/reference/libs/controllers/stanley_controller.py:138-159  long_control
+//   /root/reference/libs/vehicle_model/drive.py:128-138             10:1 hold + steering filter
+//
+// The Stanley controller's nearest-waypoint search is a global scan with "first
+// minimum wins" (strict '<' on sqrt distances).  It is kept global and exact here: the
+// scan compares squared distances (no sqrt in the loop) and falls back to comparing
+// the rounded sqrt values only for a candidate so close to the running minimum that
+// the two roundings could coincide.  The controllers run once per `ctrl_every` steps, so
+// their trigonometry uses the full-range ROCm device library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vdyn_device.hpp"
+
+namespace vdyn {
+
+template <typename T>
+struct CtrlGains {
+    T k, k_soft, max_steer, lookahead, deadband;  // stanley_controller.py:40-47
+    T kp, ki, kd;                                 // :140-143
+    T filt_keep, filt_gain;                       // drive.py:137: (1 - 1e-5/(2*0.001)), 1e-5/(2*0.001)
+};
+
+template <typename T> struct Lib;
+template <> struct Lib<float> {
+    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
+    static __device__ __forceinline__ float atan(float x) { return ::atanf(x); }
+    static __device__ __forceinline__ float fmod(float a, float b) { return ::fmodf(a, b); }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
+    static constexpr float kTieBand = 1.0f - 16.0f * 1.1920929e-07f;
+};
+template <> struct Lib<double> {
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double atan(double x) { return ::atan(x); }
+    static __device__ __forceinline__ double fmod(double a, double b) { return ::fmod(a, b); }
+    static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
+    static constexpr double kTieBand = 1.0 - 16.0 * 2.220446049250313e-16;
+};
+
+// (e + pi) % (2 pi) - pi with Python's floor-mod (stanley_controller.py:103,123)
+template <typename T>
+__device__ __forceinline__ T wrap_pi(T e)
+{
+    const T pi = T(3.141592653589793), two_pi = T(2 * 3.141592653589793);
+    T m = Lib<T>::fmod(e + pi, two_pi);
+    if (m < T(0)) m += two_pi;
+    return m - pi;
+}
+
+// Waypoint access: a table of (x, y) pairs, either staged in LDS or read through L2.
+template <typename T>
+struct Waypoints {
+    const T *base;  // this lane's table: [W][2]
+    int W;
+    __device__ __forceinline__ void get(int i, T &x, T &y) const
+    {
+        x = base[2 * i];
+        y = base[2 * i + 1];
+    }
+};
+
+// stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
+template <typename T>
+__device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Waypoints<T> &wp, T x, T y, T yaw,
+                                                T v, T &steer_out, int &idx_out, T &cte_out)
+{
+    using L = Lib<T>;
+    // :56-66 global nearest waypoint, first minimum under strict '<' of the sqrt distances
+    T best_d2 = T(INFINITY);
+    int best_i = 0;
+    for (int i = 0; i < wp.W; ++i) {
+        T wx, wy;
+        wp.get(i, wx, wy);
+        const T dx = wx - x, dy = wy - y;
+        const T d2 = dx * dx + dy * dy;
+        bool better = d2 < best_d2;
+        // sqrt is monotone, so d2 < best_d2 implies sqrt(d2) <= sqrt(best_d2); equality of the
+        // rounded roots (the reference would then keep the earlier index) is only possible
+        // within a few ulp -- settle exactly that case with the roots themselves
+        if (__builtin_expect(__any(better && d2 >= best_d2 * L::kTieBand) != 0, 0)) {
+            if (better && d2 >= best_d2 * L::kTieBand) better = L::sqrt(d2) < L::sqrt(best_d2);
+        }
+        best_d2 = better ? d2 : best_d2;
+        best_i = better ? i : best_i;
+    }
+    // :68-76 walk forward until the accumulated arc length reaches the lookahead distance
+    T total = L::sqrt(best_d2);
+    int ce = best_i;
+    T px, py;
+    wp.get(best_i, px, py);
+    for (int i = best_i + 1; i < wp.W; ++i) {
+        if (total >= G.lookahead) break;
+        T qx, qy;
+        wp.get(i, qx, qy);
+        const T ex = qx - px, ey = qy - py;
+        total += L::sqrt(ex * ex + ey * ey);
+        ce = i;
+        px = qx;
+        py = qy;
+    }
+    // :90-98 (px, py) is waypoint ce
+    T sy, cy;
+    L::sincos(yaw, &sy, &cy);
+    const T v0 = px - x - G.lookahead * cy;
+    const T v1 = py - y - G.lookahead * sy;
+    T cte = L::sqrt(v0 * v0 + v1 * v1);
+    if (cte < G.deadband) cte = T(0);
+    // :101-104
+    const T che = wrap_pi<T>(L::atan2(v1, v0) - yaw);
+    const T sign = che > T(0) ? T(1) : (che < T(0) ? T(-1) : che);  // np.sign: 0 and nan pass through
+    // :109-120 trajectory heading; wraps from the last waypoint to the first
+    T ax_, ay_, bx_, by_;
+    if (ce < wp.W - 1) {
+        ax_ = px; ay_ = py;
+        wp.get(ce + 1, bx_, by_);
+    } else {
+        wp.get(wp.W - 1, ax_, ay_);
+        wp.get(0, bx_, by_);
+    }
+    const T he = wrap_pi<T>(L::atan2(by_ - ay_, bx_ - ax_) - yaw);         // :122-123
+    T steer = he + L::atan(G.k * sign * cte / (v + G.k_soft));             // :124-126
+    steer = steer < -G.max_steer ? -G.max_steer : steer;                   // :128 np.clip
+    steer = steer > G.max_steer ? G.max_steer : steer;
+    steer_out = steer;
+    idx_out = ce;
+    cte_out = cte;
+}
+
+// stanley_controller.py:138-159
+template <typename T>
+__device__ __forceinline__ void long_control(const CtrlGains<T> &G, T desired, T current, T prev, T &total, T dt,
+                                             T &tau_out)
+{
+    const T vel_error = desired - current;
+    total = total + vel_error * dt;
+    const T p = G.kp * vel_error;
+    const T i = G.ki * total;
+    const T d = G.kd * (current - prev) / dt;
+    T tau = p + i + d;
+    if (current <= T(0.01)) tau = abs_t(tau);
+    tau_out = tau;
+}
+
+// Controller state carried between controller updates (and between launches):
+// rows of cstate [6][N]: x_del, total_vel_error, prev_vel, target_vel, delta, torque.
+template <typename T>
+struct CtrlState {
+    T x_del, total, prev_vel, target, delta, tau;
+    int idx;  // last target index (diagnostic)
+    T cte;    // last crosstrack error (diagnostic)
+};
+
+// One controller update, drive.py:128-138, from the current vehicle state s[10];
+// `steer` returns the unfiltered (limited) Stanley angle.
+template <typename T>
+__device__ __forceinline__ void controller_update(const CtrlGains<T> &G, const Waypoints<T> &wp, const T s[10],
+                                                  T dt, CtrlState<T> &c, T &steer)
+{
+    stanley_control<T>(G, wp, s[8], s[9], s[7], s[0], steer, c.idx, c.cte);  // drive.py:129-130
+    long_control<T>(G, c.target, s[0], c.prev_vel, c.total, dt, c.tau);       // :131-133
+    c.prev_vel = s[0];                                                        // :134
+    c.x_del = G.filt_keep * c.x_del + G.filt_gain * steer;                    // :137
+    c.delta = c.x_del;                                                        // :138
+}
+
+}  // namespace vdyn

@@ -42,4 +42,28 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
                              const T *goal, double dt, double w_delta, T *best_cost, int *best_idx,
                              T *cost_all, hipStream_t st);
 
+template <typename T>
+struct ClosedLoopArgs {
+    int64_t n = 0;
+    int H = 0, ctrl_every = 10, phase = 0;
+    const T *state0 = nullptr;    // [12][n]
+    const T *cstate0 = nullptr;   // [6][n]
+    const T *wp = nullptr;        // [P][Wmax][2]
+    int Wmax = 0;
+    const int *wcount = nullptr;  // [P]
+    const int *path_id = nullptr; // [n]
+    int P = 0;
+    double dt = 0;
+    T *terminal = nullptr;        // [12][n]
+    T *cstate = nullptr;          // [6][n]
+    T *log = nullptr;             // nullable [H][16][n]
+    T *ctrl_out = nullptr;        // controller_update only: [3][n]
+};
+
+template <typename T>
+hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const ClosedLoopArgs<T> &a,
+                              hipStream_t st);
+template <typename T>
+hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs<T> &a, hipStream_t st);
+
 }  // namespace vdyn

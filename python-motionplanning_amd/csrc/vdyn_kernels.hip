@@ -6,6 +6,7 @@
 // controls are read time-major so that a wave reads 64 consecutive values.
 #include "vdyn_internal.hpp"
 #include "vdyn_device.hpp"
+#include "vdyn_controls.hpp"
 
 namespace vdyn {
 
@@ -216,6 +217,123 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
     }
 }
 
+// Closed-loop rollout: the sub-step loop of drive.py:114-151 without the planner.  Every
+// `ctrl_every` steps the lane runs the Stanley + PID + filter update (vdyn_controls.hpp)
+// against its waypoint table, holds the commands in between (zero-order hold, drive.py:128)
+// and integrates with the same RK4 step as the open-loop kernel.
+//   WPLDS: all P waypoint tables fit the LDS budget and are staged there once per workgroup;
+//          otherwise the scan reads them through L2.
+//   log (nullable): [H][16][n] rows state12, delta, torque, target index, crosstrack error.
+template <typename T, bool CS, bool WPLDS>
+__global__ void __launch_bounds__(kBlock)
+closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_every, int phase,
+                   const T *__restrict__ state0, const T *__restrict__ cstate0, const T *__restrict__ wp,
+                   int Wmax, const int *__restrict__ wcount, const int *__restrict__ path_id, int Pn, T h,
+                   T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *lds_wp = reinterpret_cast<T *>(smem_raw);
+    if (WPLDS) {
+        const int total = Pn * Wmax * 2;
+        for (int i = threadIdx.x; i < total; i += kBlock) lds_wp[i] = wp[i];
+        __syncthreads();
+    }
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gid < n;
+    const int64_t r = active ? gid : n - 1;
+
+    T s[10], ax, ay;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = state0[(int64_t)i * n + r];
+    ax = state0[10 * n + r];
+    ay = state0[11 * n + r];
+    CtrlState<T> c;
+    c.x_del = cstate0[r];
+    c.total = cstate0[n + r];
+    c.prev_vel = cstate0[2 * n + r];
+    c.target = cstate0[3 * n + r];
+    c.delta = cstate0[4 * n + r];
+    c.tau = cstate0[5 * n + r];
+    c.idx = -1;
+    c.cte = T(0);
+
+    const int pid = min(max(path_id[r], 0), Pn - 1);
+    Waypoints<T> w;
+    w.base = (WPLDS ? lds_wp : wp) + (int64_t)pid * Wmax * 2;
+    w.W = min(max(wcount[pid], 1), Wmax);
+
+    for (int t = 0; t < H; ++t) {
+        if ((phase + t) % ctrl_every == 0) {   // wave-uniform test
+            T steer_raw;
+            controller_update<T>(G, w, s, h, c, steer_raw);
+        }
+        const T delta[4] = {c.delta, c.delta, T(0), T(0)};
+        const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
+        rk4_advance<T, true, false, CS>(P, s, ax, ay, delta, tq, P.mu, h, nullptr, nullptr);
+        if (log != nullptr && active) {
+            T *row = log + (int64_t)t * 16 * n + r;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) row[(int64_t)i * n] = s[i];
+            row[10 * n] = ax;
+            row[11 * n] = ay;
+            row[12 * n] = c.delta;
+            row[13 * n] = c.tau;
+            row[14 * n] = (T)c.idx;
+            row[15 * n] = c.cte;
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) terminal[(int64_t)i * n + r] = s[i];
+        terminal[10 * n + r] = ax;
+        terminal[11 * n + r] = ay;
+        cstate[r] = c.x_del;
+        cstate[n + r] = c.total;
+        cstate[2 * n + r] = c.prev_vel;
+        cstate[3 * n + r] = c.target;
+        cstate[4 * n + r] = c.delta;
+        cstate[5 * n + r] = c.tau;
+    }
+}
+
+// One controller update for n vehicles (no integration): the drop-in of
+// StanleyController.stanley_control + LongitudinalController.long_control + the filter.
+//   out [3][n]: raw (limited) Stanley steering angle, target index, crosstrack error.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+controller_kernel(CtrlGains<T> G, int64_t n, const T *__restrict__ state, const T *__restrict__ cstate0,
+                  const T *__restrict__ wp, int Wmax, const int *__restrict__ wcount,
+                  const int *__restrict__ path_id, int Pn, T h, T *__restrict__ cstate, T *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    T s[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = state[(int64_t)i * n + r];
+    CtrlState<T> c;
+    c.x_del = cstate0[r];
+    c.total = cstate0[n + r];
+    c.prev_vel = cstate0[2 * n + r];
+    c.target = cstate0[3 * n + r];
+    c.delta = cstate0[4 * n + r];
+    c.tau = cstate0[5 * n + r];
+    const int pid = min(max(path_id[r], 0), Pn - 1);
+    Waypoints<T> w;
+    w.base = wp + (int64_t)pid * Wmax * 2;
+    w.W = min(max(wcount[pid], 1), Wmax);
+    T steer;
+    controller_update<T>(G, w, s, h, c, steer);
+    cstate[r] = c.x_del;
+    cstate[n + r] = c.total;
+    cstate[2 * n + r] = c.prev_vel;
+    cstate[3 * n + r] = c.target;
+    cstate[4 * n + r] = c.delta;
+    cstate[5 * n + r] = c.tau;
+    out[r] = steer;
+    out[n + r] = (T)c.idx;
+    out[2 * n + r] = c.cte;
+}
+
 // ---------------------------------------------------------------- launchers ---------
 
 template <typename T>
@@ -325,12 +443,61 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
     return hipGetLastError();
 }
 
+template <typename T>
+static CtrlGains<T> make_gains(const VdynCtrlGains &g)
+{
+    CtrlGains<T> c;
+    c.k = (T)g.k; c.k_soft = (T)g.k_soft; c.max_steer = (T)g.max_steer;
+    c.lookahead = (T)g.lookahead; c.deadband = (T)g.deadband;
+    c.kp = (T)g.kp; c.ki = (T)g.ki; c.kd = (T)g.kd;
+    c.filt_keep = (T)(1 - g.filter_gain);   // drive.py:137
+    c.filt_gain = (T)g.filter_gain;
+    return c;
+}
+
+template <typename T>
+hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const ClosedLoopArgs<T> &a,
+                              hipStream_t st)
+{
+    if (a.n <= 0) return hipSuccess;
+    const DevParams<T> P = make_dev_params<T>(p, nullptr);
+    const CtrlGains<T> G = make_gains<T>(g);
+    const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    const size_t wp_bytes = (size_t)a.P * a.Wmax * 2 * sizeof(T);
+    const bool lds = wp_bytes <= 64 * 1024;
+    const bool cs = shape_factors_small(p);
+#define VDYN_CL(CSV, LDSV)                                                                            \
+    hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV>), dim3(grid), dim3(kBlock), LDSV ? wp_bytes : 0, \
+                       st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0, a.cstate0, a.wp, a.Wmax,   \
+                       a.wcount, a.path_id, a.P, (T)a.dt, a.terminal, a.cstate, a.log)
+    if (cs && lds) VDYN_CL(true, true);
+    else if (cs) VDYN_CL(true, false);
+    else if (lds) VDYN_CL(false, true);
+    else VDYN_CL(false, false);
+#undef VDYN_CL
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs<T> &a, hipStream_t st)
+{
+    if (a.n <= 0) return hipSuccess;
+    const CtrlGains<T> G = make_gains<T>(g);
+    const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((controller_kernel<T>), dim3(grid), dim3(kBlock), 0, st, G, a.n, a.state0, a.cstate0,
+                       a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.cstate, a.ctrl_out);
+    return hipGetLastError();
+}
+
 #define VDYN_INSTANTIATE(T)                                                                          \
     template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
                                                const T *, T *, T *, T *, T *, hipStream_t);          \
     template hipError_t launch_mpc_argmin<T>(const VdynParams &, int, int, int, const T *, const T *, \
-                                             const T *, double, double, T *, int *, T *, hipStream_t);
+                                             const T *, double, double, T *, int *, T *, hipStream_t); \
+    template hipError_t launch_closed_loop<T>(const VdynParams &, const VdynCtrlGains &,             \
+                                              const ClosedLoopArgs<T> &, hipStream_t);               \
+    template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t);
 VDYN_INSTANTIATE(float)
 VDYN_INSTANTIATE(double)
 

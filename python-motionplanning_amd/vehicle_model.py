@@ -321,6 +321,63 @@ class VehicleModel:
             *be.stream_args())
         return (bc, bi, costs) if return_costs else (bc, bi)
 
+    # ------------------------------------------------- controllers either side of the path
+    def _closed_loop_inputs(self, be, states, cstate, waypoints, wcount, path_id):
+        st = be.inp(states)
+        if st.ndim != 2 or st.shape[0] != 12:
+            raise ValueError("states must be [12][N]")
+        n = st.shape[1]
+        cs = be.inp(cstate, shape=(6, n))
+        wp = be.inp(waypoints)
+        if wp.ndim == 2:
+            wp = wp[None]
+        if wp.ndim != 3 or wp.shape[2] != 2 or wp.shape[1] < 1:
+            raise ValueError("waypoints must be [P][Wmax][2] (x, y)")
+        P, Wmax = int(wp.shape[0]), int(wp.shape[1])
+        wc = np.full(P, Wmax, dtype=np.int32) if wcount is None else np.ascontiguousarray(wcount, dtype=np.int32)
+        if wc.shape != (P,) or wc.min() < 1 or wc.max() > Wmax:
+            raise ValueError("wcount must be [P] with 1 <= wcount <= Wmax")
+        wc = be.inp(wc, int32=True)
+        pid = be.inp(np.zeros(n, dtype=np.int32) if path_id is None else path_id, shape=(n,), int32=True)
+        if not be.torch and n and (int(pid.min()) < 0 or int(pid.max()) >= P):
+            raise ValueError("path_id out of range")
+        return st, n, cs, wp.contiguous() if be.torch else np.ascontiguousarray(wp), P, Wmax, wc, pid
+
+    def controller_update(self, states, cstate, waypoints, wcount=None, path_id=None, gains=None, dt=None):
+        """One Stanley + PID + steering-filter update for N vehicles (drive.py:128-138).
+
+        ``states [12][N]``; ``cstate [6][N]`` rows ``x_del, total_vel_error, prev_vel,
+        target_vel, delta, torque``; ``waypoints [P][Wmax][2]``.  Returns the new
+        ``cstate [6][N]`` and ``out [3][N]`` = (limited Stanley angle before the filter,
+        target index, crosstrack error)."""
+        be = _Backend(states)
+        st, n, cs, wp, P, Wmax, wc, pid = self._closed_loop_inputs(be, states, cstate, waypoints, wcount, path_id)
+        g = gains if gains is not None else _lib.default_ctrl_gains()
+        cso, out = be.out(6, n), be.out(3, n)
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_controller_update_{be.suffix}_{be.kind}", C.byref(g), n, _vp(st), _vp(cs), _vp(wp), Wmax,
+            _vp(wc), _vp(pid), P, float(self.dt if dt is None else dt), _vp(cso), _vp(out), *be.stream_args())
+        return cso, out
+
+    def closed_loop(self, states0, cstate0, waypoints, H, wcount=None, path_id=None, gains=None, dt=None,
+                    ctrl_every=10, phase=0, log=False):
+        """H sub-steps of the reference's Car.drive loop (drive.py:114-151) minus the planner:
+        controllers every ``ctrl_every`` steps (zero-order hold), RK4 every step.
+        Returns ``terminal [12][N]``, ``cstate [6][N]`` (and ``log [H][16][N]``: state12, delta,
+        torque, target index, crosstrack error)."""
+        be = _Backend(states0)
+        st, n, cs, wp, P, Wmax, wc, pid = self._closed_loop_inputs(be, states0, cstate0, waypoints, wcount, path_id)
+        if H < 0 or ctrl_every <= 0 or phase < 0:
+            raise ValueError("need H >= 0, ctrl_every > 0, phase >= 0")
+        g = gains if gains is not None else _lib.default_ctrl_gains()
+        term, cso = be.out(12, n), be.out(6, n)
+        lg = be.out(int(H), 16, n) if log else None
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_closed_loop_{be.suffix}_{be.kind}", C.byref(g), n, int(H), int(ctrl_every), int(phase),
+            _vp(st), _vp(cs), _vp(wp), Wmax, _vp(wc), _vp(pid), P, float(self.dt if dt is None else dt),
+            _vp(term), _vp(cso), _vp(lg), *be.stream_args())
+        return (term, cso, lg) if log else (term, cso)
+
     def synchronize(self, device=None):
         """Wait for the default stream of `device` (NumPy calls are already synchronous)."""
         d = self.device if device is None else device

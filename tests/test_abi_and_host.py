@@ -29,7 +29,7 @@ def lib(pkg):
 
 def test_header_symbols_all_exported(lib):
     syms = declared_symbols()
-    assert len(syms) == 8 + 2 * 8, syms
+    assert len(syms) == 9 + 2 * 12, syms
     dll = ctypes.CDLL(lib.LIB_PATH)
     for s in syms:
         assert hasattr(dll, s), f"{s} declared in include/vdyn.h but not exported"
@@ -46,7 +46,7 @@ def test_library_carries_gfx950_code_only(lib):
 
 
 def test_params_struct_and_defaults(lib):
-    assert ctypes.sizeof(lib.VdynParams) == 19 * 8
+    assert ctypes.sizeof(lib.VdynParams) == 19 * 8 and ctypes.sizeof(lib.VdynCtrlGains) == 9 * 8
     assert lib.load().vdyn_abi_version() == lib.VDYN_ABI_VERSION
     p = lib.default_params()
     # SURVEY.md section 8(a1), measured on the reference's VehicleParameters()

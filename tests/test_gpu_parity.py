@@ -341,3 +341,107 @@ def test_torch_stream_and_dtypes(gpu_vm, workloads):
     t32 = vm.rollout(torch.from_numpy(s0).to(dev).float(), torch.from_numpy(ctrl).to(dev).float())
     assert t32.dtype == torch.float32
     assert np.array_equal(t32.cpu().numpy(), vm.rollout(s0.astype(np.float32), ctrl.astype(np.float32)))
+
+
+# ---- "next" row 1: controllers either side of the path -----------------------------------------
+def _g9_gains(pkg, g):
+    L = pkg._lib
+    gg = L.default_ctrl_gains()
+    for name, v in zip(("k", "k_soft", "max_steer", "lookahead", "deadband", "kp", "ki", "kd"), g["gains"]):
+        setattr(gg, name, float(v))
+    return gg
+
+
+def test_g9_controller_dropins(gpu_vm, pkg):
+    """StanleyController.stanley_control / LongitudinalController.long_control with the
+    reference's signatures, on every call the reference's Car.drive made in 3 frames."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    ga = g["gains"]
+    sc = pkg.StanleyController(ga[0], ga[1], 0, 0, ga[2], 2.906)
+    lc = pkg.LongitudinalController(ga[5], ga[6], ga[7])
+    for i in range(len(g["stanley_in"])):
+        f = int(g["stanley_wp"][i])
+        sc.update_waypoints([list(r) for r in g["waypoints"][f, :g["waypoint_count"][f]]])
+        d, idx, cte = sc.stanley_control(*g["stanley_in"][i])
+        assert idx == int(g["stanley_out"][i, 1])
+        assert abs(d - g["stanley_out"][i, 0]) <= 1e-11 and abs(cte - g["stanley_out"][i, 2]) <= 1e-11
+        tot, tq = lc.long_control(*g["pid_in"][i])
+        assert len(tq) == 4 and tq[0] == tq[3]
+        assert abs(tot - g["pid_out"][i, 0]) <= 1e-14 and abs(tq[0] - g["pid_out"][i, 1]) <= 1e-10
+
+
+def test_g9_closed_loop_three_frames(gpu_vm, pkg):
+    """Controllers + filter + RK4 in one launch per planning cycle reproduce the reference's
+    closed-loop trajectory (300 sub-steps of Car.drive), fp64 and fp32."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    dt = float(g["dt"])
+    vm = gpu_vm(dt)
+    gains = _g9_gains(pkg, g)
+    for dtype, tol_s, tol_d in ((np.float64, 1e-9, 1e-9), (np.float32, 1e-3, 1e-3)):
+        s = np.concatenate([g["state"], g["ax_ay_prev"]])[:, None].astype(dtype)
+        c = np.array([g["x_del"], g["total_vel_error"], g["prev_vel"], g["target_vel"], 0.0, 0.0])[:, None]
+        c = c.astype(dtype)
+        for f in range(3):
+            wp = g["waypoints"][f, :g["waypoint_count"][f], :2].astype(dtype)
+            s, c, log = vm.closed_loop(s, c, wp, 100, gains=gains, log=True)
+            want = g["rk4_log"][f * 100:(f + 1) * 100]
+            # rows judged against their own magnitude; the two body accelerations hover around
+            # zero on this straight (0.08 m/s^2), so they are judged against 1 m/s^2
+            scale = np.maximum(np.abs(want[:, :12]).max(axis=0), [1e-3] * 10 + [1.0, 1.0])
+            assert (np.abs(log[:, :12, 0] - want[:, :12]) <= tol_s * scale).all()
+            assert np.abs(log[:, 12, 0] - want[:, 12]).max() <= tol_d * max(np.abs(want[:, 12]).max(), 1e-3)
+            # torque = 1000 (v_target - U) + ...: the PID gain multiplies U's rounding (fp32: 2e-6 * 1000)
+            tol_tq = 1e-6 if dtype == np.float64 else 5e-2
+            assert np.abs(log[:, 13, 0] - want[:, 13]).max() <= tol_tq
+            if dtype == np.float64:
+                assert np.array_equal(log[::10, 14, 0], g["stanley_out"][f * 10:(f + 1) * 10, 1])
+            assert np.array_equal(log[-1, :12], s)
+
+
+def test_closed_loop_batch_vs_oracle_and_properties(gpu_vm, pkg, oracle):
+    """512 perturbed vehicles tracking 3 shared waypoint tables (LDS-staged), 120 sub-steps:
+    vs the oracle; one launch == chained launches with the phase carried; fp32 within 1e-3."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    dt = 1e-3
+    vm = gpu_vm(dt)
+    gains = _g9_gains(pkg, g)
+    cp = oracle.ctrl_params(*g["gains"])
+    rng = np.random.default_rng(3)
+    n, P = 512, 3
+    wc = np.array([700, 650, 500], dtype=np.int32)
+    wp = np.zeros((P, 700, 2))
+    for p in range(P):
+        wp[p, :wc[p]] = g["waypoints"][p, 400:400 + wc[p] * 3:3, :2]        # 3 cm spacing, ~20 m
+    pid = rng.integers(0, P, n).astype(np.int32)
+    s0 = np.tile(np.concatenate([g["state"], [0.0, 0.0]])[:, None], (1, n))
+    s0[0] += rng.uniform(-3, 3, n)
+    s0[3:7] = s0[0] / 0.308309813617345
+    s0[7] += rng.normal(0, 0.03, n)
+    s0[8] += rng.uniform(0.0, 4.0, n)
+    s0[9] += rng.normal(0, 0.5, n)
+    c0 = np.zeros((6, n))
+    c0[2] = s0[0]
+    c0[3] = 25.0
+    term, cs, log = vm.closed_loop(s0, c0, wp, 120, wcount=wc, path_id=pid, gains=gains, log=True)
+    ot, oc, olog = oracle.closed_loop(oracle.default_params(), cp, s0, c0, wp, wc, pid, dt, 120, log=True,
+                                      nthreads=8)
+    assert np.array_equal(log[:, 14], olog[:, 14]), "target indices must match the oracle exactly"
+    assert parity(term, ot, F64_TOL) <= 1e-9
+    assert parity(cs[[0, 1, 2, 4, 5]], oc[[0, 1, 2, 4, 5]], F64_TOL) <= 1e-9
+    # chained launches with the sub-step phase carried == one launch, bit for bit
+    a, ca = vm.closed_loop(s0, c0, wp, 47, wcount=wc, path_id=pid, gains=gains)
+    b, cb = vm.closed_loop(a, ca, wp, 73, wcount=wc, path_id=pid, gains=gains, phase=47)
+    assert np.array_equal(b, term) and np.array_equal(cb, cs)
+    # table too large for LDS -> L2 path, same numbers
+    big = np.zeros((P, 9000, 2))
+    big[:, :700] = wp
+    t2, c2 = vm.closed_loop(s0, c0, big, 120, wcount=wc, path_id=pid, gains=gains)
+    assert np.array_equal(t2, term) and np.array_equal(c2, cs)
+    # fp32
+    t32, c32 = vm.closed_loop(s0.astype(np.float32), c0.astype(np.float32), wp.astype(np.float32), 120,
+                              wcount=wc, path_id=pid, gains=gains)
+    e = parity(t32, ot, F32_TOL, "closed loop fp32")
+    print(f"\n  closed loop fp32 row-relative err {e:.2e}")
+    # batched controller update == first controller step of the closed loop
+    cu, out = vm.controller_update(s0, c0, wp, wcount=wc, path_id=pid, gains=gains)
+    assert np.array_equal(out[1], log[0, 14]) and np.array_equal(cu[4], log[0, 12])
