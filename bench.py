@@ -245,6 +245,15 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = timed_launches(lambda: vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA), 5, torch)
     ex["config5_mpc_1024x512x50_f32"] = {"steps_per_s": E * C * H / t, "kernel_ms": t * 1e3,
                                          "rollouts_per_s": E * C / t}
+    # closed loop: Stanley + PID every 10 sub-steps against 7 LDS-staged
+    # waypoint tables of 1024 points, RK4 every sub-step
+    cl = [torch.from_numpy(a).to(dev) for a in W.closed_loop_config(N_PER_GPU, dtype=np.float32)]
+    run_cl = lambda: vm.closed_loop(cl[0], cl[1], cl[2], HORIZON, wcount=cl[3], path_id=cl[4])
+    run_cl()
+    t = timed_launches(run_cl, 3, torch)
+    ex["closed_loop_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3,
+                                       "controller_updates_per_s": n / 10 / t, "waypoints_per_table": 1024}
+    del cl
     # the same workload through the HOST-pointer ABI (staging copies over PCIe included)
     s0_h, pid_h = s0.cpu().numpy(), pid.cpu().numpy()
     vm.rollout(s0_h, tab, path_id=pid_h)

@@ -54,6 +54,15 @@ typedef struct OracleCtrlParams {
                                const REAL *cstate0, const REAL *wp, int Wmax, const int *wcount,        \
                                const int *path_id, int P, REAL *terminal, REAL *cstate, REAL *log,      \
                                int nthreads);                                                           \
+    int oracle_collision_check_##S(const REAL *x, const REAL *y, const REAL *yaw, int L,                \
+                                   long point_stride, const REAL *obst, int M, const double *offsets,  \
+                                   const double *radii, int nc);                                        \
+    int oracle_select_best_path_##S(int E, int P, int L, const REAL *x, const REAL *y, const REAL *yaw, \
+                                    long ego_stride, long path_stride, long point_stride,              \
+                                    const REAL *obst, int M, long obst_ego_stride,                     \
+                                    const double *offsets, const double *radii, int nc,                \
+                                    const REAL *goal, double weight, int *collision_free,              \
+                                    int *best_idx, REAL *best_score, int nthreads);                    \
     int oracle_mpc_argmin_##S(const OracleParams *p, int E, int C, int H, double dt,           \
                               const REAL *ego, const REAL *cand, const REAL *goal,             \
                               REAL w_delta, REAL *best_cost, int *best_idx, REAL *cost_all,    \

@@ -124,6 +124,43 @@ def config5(E=1024, C=512, H=50, dtype=np.float32,
     return ego.astype(dtype), cand.astype(dtype), goal.astype(dtype)
 
 
+def closed_loop_config(n=65536, P=NUM_PATHS, W=1024, ds=0.03, dtype=np.float32, seed=20243):
+    """Closed-loop tracking workload: P constant-curvature
+    waypoint tables of W points at `ds` spacing (kappa_k = 0.004 (k - P//2) 1/m, all starting
+    at the origin heading +x), n vehicles spread over the first metres of their table with
+    lateral / heading / speed perturbations.  Returns state0 [12][n], cstate0 [6][n]
+    (x_del, total_vel_error, prev_vel, target_vel, delta, torque), wp [P][W][2], wcount [P],
+    path_id [n]."""
+    rng = np.random.default_rng(seed)
+    s_arc = np.arange(W) * ds
+    wp = np.empty((P, W, 2))
+    for k in range(P):
+        kap = 0.004 * (k - P // 2)
+        if kap == 0.0:
+            wp[k, :, 0], wp[k, :, 1] = s_arc, 0.0
+        else:
+            wp[k, :, 0] = np.sin(kap * s_arc) / kap
+            wp[k, :, 1] = (1.0 - np.cos(kap * s_arc)) / kap
+    pid = (np.arange(n) % P).astype(np.int32)
+    kap = 0.004 * (pid - P // 2)
+    s_along = rng.uniform(0.0, 5.0, n)
+    lat = rng.normal(0.0, 0.3, n)
+    th = kap * s_along
+    cx = np.where(kap == 0.0, s_along, np.sin(th) / np.where(kap == 0.0, 1.0, kap))
+    cy = np.where(kap == 0.0, 0.0, (1.0 - np.cos(th)) / np.where(kap == 0.0, 1.0, kap))
+    U = rng.uniform(15.0, 30.0, n)
+    st = np.zeros((NSTATE, n))
+    st[0] = U
+    st[3:7] = U / DEFAULT_RW
+    st[7] = th + rng.normal(0.0, 0.02, n)
+    st[8] = cx - lat * np.sin(th)
+    st[9] = cy + lat * np.cos(th)
+    cs = np.zeros((6, n))
+    cs[2] = U          # prev_vel (drive.py:50)
+    cs[3] = 25.0       # target_vel (drive.py:46,51)
+    return (st.astype(dtype), cs.astype(dtype), wp.astype(dtype), np.full(P, W, dtype=np.int32), pid)
+
+
 MPC_W_DELTA = 1e-3  # weight of sum(delta^2) in the config-5 cost
 
 

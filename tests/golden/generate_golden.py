@@ -350,7 +350,69 @@ def g9():
           "idx range", int(np.min(np.array(st_out)[:, 1])), int(np.max(np.array(st_out)[:, 1])))
 
 
+_G10_SEEN, _G10_ORIG = [], []
+
+
+def _g10_spy_select(self, paths, arr, goal_state):
+    o = _G10_ORIG[0](self, paths, arr, goal_state)
+    _G10_SEEN.append((np.array(paths, dtype=np.float64), np.array(arr, dtype=bool),
+                      np.array(goal_state, dtype=np.float64), -1 if o is None else int(o)))
+    return o
+
+
+def g10():
+    """Collision check + best-path selection (collision_checker.py:32-117,134-203) on the 7
+    lattice paths the reference's planner produced in 3 frames of Car.drive, against the
+    world obstacle and 60 seeded re-placements of it (so that 0..7 paths collide)."""
+    import scipy.integrate
+    if not hasattr(scipy.integrate, "cumtrapz"):
+        scipy.integrate.cumtrapz = scipy.integrate.cumulative_trapezoid
+    import libs.vehicle_model.drive as drive
+    from libs.utils.env import world
+    from libs.motionplanner.collision_checker import CollisionChecker
+    drive.os.system = lambda *_a, **_k: 0
+    path = world.path
+    car = drive.Car(path.px[10], path.py[10], path.pyaw[10], path.px, path.py, path.pyaw,
+                    0.01 / drive.Veh_SIM_NUM)
+    # patched on the class (the planner pickles the checker instance into its process pool)
+    seen = _G10_SEEN
+    _G10_ORIG.append(CollisionChecker.select_best_path_index)
+    CollisionChecker.select_best_path_index = _g10_spy_select
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for fr in range(3):
+            car.drive(fr)
+    CollisionChecker.select_best_path_index = _G10_ORIG[0]
+    obstacle0 = np.array(world.obstacle_xy, dtype=np.float64)
+    chk = CollisionChecker(drive.CIRCLE_OFFSETS, drive.CIRCLE_RADII, drive.PATH_SELECT_WEIGHT)
+    rng = np.random.default_rng(10)
+    paths_l, obst_l, free_l, best_l, goal_l = [], [], [], [], []
+    for paths, arr, goal, best in seen:                 # the planner's own calls
+        paths_l.append(paths); obst_l.append(obstacle0); free_l.append(arr); best_l.append(best)
+        goal_l.append(goal[:2])
+    base_paths, base_goal = seen[0][0], seen[0][2]
+    centre = obstacle0.mean(axis=0)
+    for _ in range(60):                                  # seeded obstacle re-placements
+        shift = np.array([rng.uniform(-25, 10), rng.uniform(-6, 12)])
+        ob = obstacle0 - centre + centre + shift
+        arr = [bool(chk.collision_check(list(base_paths[i]), ob)) for i in range(len(base_paths))]
+        best = chk.select_best_path_index(base_paths, arr, base_goal)
+        paths_l.append(base_paths); obst_l.append(ob); free_l.append(np.array(arr)); goal_l.append(base_goal[:2])
+        best_l.append(-1 if best is None else int(best))
+    for i in range(3):                                   # the reference's own array agrees with a direct call
+        direct = [bool(chk.collision_check(list(paths_l[i][k]), obst_l[i])) for k in range(7)]
+        assert direct == list(free_l[i])
+    np.savez_compressed(os.path.join(HERE, "g10_collision_select.npz"), paths=np.array(paths_l),
+                        obstacles=np.array(obst_l), collision_free=np.array(free_l), best_index=np.array(best_l),
+                        goal=np.array(goal_l), circle_offsets=np.array(drive.CIRCLE_OFFSETS, dtype=np.float64),
+                        circle_radii=np.array(drive.CIRCLE_RADII, dtype=np.float64),
+                        weight=np.float64(drive.PATH_SELECT_WEIGHT))
+    fr = np.array(free_l)
+    print("G10 cases", len(paths_l), "paths shape", np.array(paths_l).shape, "free counts histogram",
+          np.bincount(fr.sum(axis=1), minlength=8), "best", np.bincount(np.array(best_l) + 1, minlength=8))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -220,3 +220,18 @@ def test_g9_closed_loop_three_frames(oracle):
         idx = g["stanley_out"][f * 10:(f + 1) * 10, 1]
         assert np.array_equal(log[::10, 14, 0], idx)
     assert abs(c[0, 0] - g["x_del_log"][-1]) <= 1e-14
+
+
+# ---- "next" row 2: collision check + best-path selection (G10) --------------------------------
+def test_g10_collision_and_selection(oracle):
+    g = load_golden("g10_collision_select.npz")
+    E = len(g["paths"])
+    free, bi, bs = oracle.select_best_path(g["paths"], g["obstacles"], g["goal"].T.copy(),
+                                           g["circle_offsets"], g["circle_radii"], float(g["weight"]))
+    assert np.array_equal(free, g["collision_free"])
+    assert np.array_equal(bi, g["best_index"])
+    assert np.isinf(bs[bi < 0]).all() and np.isfinite(bs[bi >= 0]).all()
+    # shared obstacle set == per-ego copies of it
+    f2, b2, s2 = oracle.select_best_path(g["paths"][:3], g["obstacles"][0], g["goal"][:3].T.copy())
+    assert np.array_equal(f2, g["collision_free"][:3]) and np.array_equal(b2, g["best_index"][:3])
+    assert E == 63
