@@ -230,6 +230,49 @@ int vdyn_closed_loop_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, 
                               int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
                               double dt, float *terminal, float *cstate_out, float *log);
 
+/* ==== "next" row: collision check + best-path selection ===================================
+ * Replaces: CollisionChecker.collision_check (collision_checker.py:32-117, one call per path;
+ * the process pool of local_planner.py:369-374 becomes lanes) and
+ * CollisionChecker.select_best_path_index (collision_checker.py:134-203), for E egos x P
+ * candidate paths of L points each.
+ * Circles of radius radii[c] sit at offsets[c] along the heading of every path point (:88-89;
+ * drive.py:25-26: offsets -1, 1, 3 m, radii 1.5 m); a path is in collision when any obstacle
+ * point lies strictly inside any circle (:104-106).  score = ||end - goal|| + weight *
+ * sum over colliding paths j of ||end_i - end_j|| (:175,:183-186), inf for colliding paths
+ * (:190-191); best = lowest score, lowest index on ties (:194-196); none free -> -1 (:163).
+ *   _dev : x, y, yaw are separate pointers with strides (in elements): path point (e, p, j) is
+ *          at [e*ego_stride + p*path_stride + j*point_stride], so the trajectory output of
+ *          vdyn_rollout_* ([L][12][N]: x = traj + 8 N, y = traj + 9 N, yaw = traj + 7 N,
+ *          point_stride = 12 N, path_stride = 1, ego_stride = P) is consumed in place.
+ *   _host: paths [E][P][3][L] = the reference's path lists [x_points, y_points, t_points].
+ *   obst [M][2] shared by all egos (obst_per_ego = 0) or [E][M][2]; circle_offsets / radii are
+ *   HOST arrays of nc <= 8 doubles; P <= 64; goal [2][E].
+ *   collision_in (nullable) [E][P]: flags the caller already has (1 = free); the check is then
+ *   skipped and only select_best_path_index runs (its collision_check_array argument, :134).
+ * -> collision_free [E][P] (1 = free), best_idx [E], best_score [E].                          */
+int vdyn_select_best_path_f64_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *x,
+                                  const double *y, const double *yaw, int64_t ego_stride, int64_t path_stride,
+                                  int64_t point_stride, const double *obst, int32_t M, int32_t obst_per_ego,
+                                  const double *circle_offsets, const double *circle_radii, int32_t nc,
+                                  const double *goal, double weight, const int32_t *collision_in,
+                                  int32_t *collision_free, int32_t *best_idx, double *best_score, void *stream);
+int vdyn_select_best_path_f32_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const float *x,
+                                  const float *y, const float *yaw, int64_t ego_stride, int64_t path_stride,
+                                  int64_t point_stride, const float *obst, int32_t M, int32_t obst_per_ego,
+                                  const double *circle_offsets, const double *circle_radii, int32_t nc,
+                                  const float *goal, double weight, const int32_t *collision_in,
+                                  int32_t *collision_free, int32_t *best_idx, float *best_score, void *stream);
+int vdyn_select_best_path_f64_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *paths,
+                                   const double *obst, int32_t M, int32_t obst_per_ego,
+                                   const double *circle_offsets, const double *circle_radii, int32_t nc,
+                                   const double *goal, double weight, const int32_t *collision_in,
+                                   int32_t *collision_free, int32_t *best_idx, double *best_score);
+int vdyn_select_best_path_f32_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const float *paths,
+                                   const float *obst, int32_t M, int32_t obst_per_ego,
+                                   const double *circle_offsets, const double *circle_radii, int32_t nc,
+                                   const float *goal, double weight, const int32_t *collision_in,
+                                   int32_t *collision_free, int32_t *best_idx, float *best_score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,13 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_closed_loop_{_s}_dev"] = (_int, _cl + [_vp])
     SIGNATURES[f"vdyn_closed_loop_{_s}_host"] = (_int, _cl)
 
+for _s in ("f32", "f64"):
+    SIGNATURES[f"vdyn_select_best_path_{_s}_dev"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64,
+                                                            _vp, _i32, _i32, _vp, _vp, _i32, _vp, _dbl, _vp, _vp,
+                                                            _vp, _vp, _vp])
+    SIGNATURES[f"vdyn_select_best_path_{_s}_host"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp,
+                                                             _vp, _i32, _vp, _dbl, _vp, _vp, _vp, _vp])
+
 _lib = None
 
 

@@ -442,6 +442,60 @@ vdyn::ClosedLoopArgs<T> cl_args(int64_t n, int32_t H, int32_t ctrl_every, int32_
 }
 
 template <typename T>
+int select_dev(VdynHandle *h, const vdyn::SelectArgs<T> &a, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (a.E < 0 || a.P <= 0 || a.L <= 0 || a.M < 0) return h->fail(VDYN_ERR_ARG, "select_best_path: bad E / P / L / M");
+    if (a.P > 64) return h->fail(VDYN_ERR_ARG, "select_best_path: at most 64 paths per ego");
+    if (a.nc <= 0 || a.nc > 8 || !a.offsets || !a.radii)
+        return h->fail(VDYN_ERR_ARG, "select_best_path: need 1..8 circles (host offsets / radii)");
+    if (a.E == 0) return VDYN_OK;
+    if (!a.x || !a.y || !a.yaw || !a.goal || !a.collision_free || !a.best_idx || !a.best_score || (a.M > 0 && !a.obst))
+        return h->fail(VDYN_ERR_ARG, "select_best_path: null buffer");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_select_best_path<T>(a, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int select_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, const T *obst, int32_t M,
+                int32_t obst_per_ego, const double *offsets, const double *radii, int32_t nc, const T *goal,
+                double weight, const int32_t *collision_in, int32_t *collision_free, int32_t *best_idx,
+                T *best_score)
+{
+    if (!h) return VDYN_ERR_ARG;
+    vdyn::SelectArgs<T> a;
+    a.E = E; a.P = P; a.L = L; a.M = M; a.offsets = offsets; a.radii = radii; a.nc = nc; a.weight = weight;
+    a.ego_stride = (int64_t)P * 3 * L; a.path_stride = 3 * (int64_t)L; a.point_stride = 1;
+    a.obst_ego_stride = obst_per_ego ? 2 * (int64_t)M : 0;
+    if (E <= 0 || P <= 0 || L <= 0 || M < 0 || !paths || !goal || !collision_free || !best_idx || !best_score ||
+        (M > 0 && !obst)) {
+        if (E == 0) return VDYN_OK;
+        return h->fail(VDYN_ERR_ARG, "select_best_path: bad size or null buffer");
+    }
+    Stage s(h);
+    const size_t i0 = s.in(paths, sizeof(T) * (size_t)E * P * 3 * L),
+                 i1 = s.in(obst, sizeof(T) * 2 * (size_t)M * (obst_per_ego ? E : 1)),
+                 i2 = s.in(goal, sizeof(T) * 2 * (size_t)E),
+                 i3 = s.in(collision_in, sizeof(int32_t) * (size_t)E * P);
+    const size_t o0 = s.out(collision_free, sizeof(int32_t) * (size_t)E * P),
+                 o1 = s.out(best_idx, sizeof(int32_t) * (size_t)E), o2 = s.out(best_score, sizeof(T) * (size_t)E);
+    int rc = s.upload();
+    if (rc) return rc;
+    const T *base = s.dev<T>(i0, false);
+    a.x = base; a.y = base + L; a.yaw = base + 2 * (int64_t)L;
+    a.obst = s.dev<T>(i1, false);
+    a.goal = s.dev<T>(i2, false);
+    a.collision_in = s.dev<int>(i3, false);
+    a.collision_free = s.dev<int>(o0, true);
+    a.best_idx = s.dev<int>(o1, true);
+    a.best_score = s.dev<T>(o2, true);
+    rc = select_dev<T>(h, a, h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
 vdyn::RolloutArgs<T> step_args(int64_t n, const T *state_in, const T *ctrl, int k, double dt,
                                const double *mu4, T *state_out, T *state_dot, T *outputs)
 {
@@ -559,7 +613,36 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
                                    false);                                                               \
     }
 
+#define VDYN_DEFINE_SELECT_ABI(S, T)                                                                     \
+    extern "C" int vdyn_select_best_path_##S##_dev(                                                      \
+        VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *x, const T *y, const T *yaw,            \
+        int64_t ego_stride, int64_t path_stride, int64_t point_stride, const T *obst, int32_t M,         \
+        int32_t obst_per_ego, const double *circle_offsets, const double *circle_radii, int32_t nc,      \
+        const T *goal, double weight, const int32_t *collision_in, int32_t *collision_free,              \
+        int32_t *best_idx, T *best_score, void *stream)                                                                                    \
+    {                                                                                                    \
+        vdyn::SelectArgs<T> a;                                                                           \
+        a.E = E; a.P = P; a.L = L; a.x = x; a.y = y; a.yaw = yaw; a.ego_stride = ego_stride;             \
+        a.path_stride = path_stride; a.point_stride = point_stride; a.obst = obst; a.M = M;              \
+        a.obst_ego_stride = obst_per_ego ? 2 * (int64_t)M : 0; a.offsets = circle_offsets;               \
+        a.radii = circle_radii; a.nc = nc; a.goal = goal; a.weight = weight;                             \
+        a.collision_in = collision_in; a.collision_free = collision_free; a.best_idx = best_idx;         \
+        a.best_score = best_score;                                                                       \
+        return select_dev<T>(h, a, stream);                                                              \
+    }                                                                                                    \
+    extern "C" int vdyn_select_best_path_##S##_host(                                                     \
+        VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, const T *obst, int32_t M,        \
+        int32_t obst_per_ego, const double *circle_offsets, const double *circle_radii, int32_t nc,      \
+        const T *goal, double weight, const int32_t *collision_in, int32_t *collision_free,              \
+        int32_t *best_idx, T *best_score)                                                                \
+    {                                                                                                    \
+        return select_host<T>(h, E, P, L, paths, obst, M, obst_per_ego, circle_offsets, circle_radii, nc, \
+                              goal, weight, collision_in, collision_free, best_idx, best_score);                       \
+    }
+
 VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
+VDYN_DEFINE_SELECT_ABI(f32, float)
+VDYN_DEFINE_SELECT_ABI(f64, double)
 VDYN_DEFINE_CTRL_ABI(f32, float)
 VDYN_DEFINE_CTRL_ABI(f64, double)

@@ -66,4 +66,25 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
 template <typename T>
 hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs<T> &a, hipStream_t st);
 
+template <typename T>
+struct SelectArgs {
+    int E = 0, P = 0, L = 0;
+    const T *x = nullptr, *y = nullptr, *yaw = nullptr;   // element (e,p,j) at e*ego + p*path + j*point
+    int64_t ego_stride = 0, path_stride = 0, point_stride = 0;
+    const T *obst = nullptr;                               // [M][2] (+ e*obst_ego_stride)
+    int M = 0;
+    int64_t obst_ego_stride = 0;
+    const double *offsets = nullptr, *radii = nullptr;     // host, nc entries
+    int nc = 0;
+    const T *goal = nullptr;                               // [2][E]
+    double weight = 0;
+    const int *collision_in = nullptr;                     // nullable [E][P]: skip the check, use these flags
+    int *collision_free = nullptr;                         // [E][P]
+    int *best_idx = nullptr;                               // [E]
+    T *best_score = nullptr;                               // [E]
+};
+
+template <typename T>
+hipError_t launch_select_best_path(const SelectArgs<T> &a, hipStream_t st);
+
 }  // namespace vdyn

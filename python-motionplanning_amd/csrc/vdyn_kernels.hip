@@ -334,6 +334,96 @@ controller_kernel(CtrlGains<T> G, int64_t n, const T *__restrict__ state, const 
     out[2 * n + r] = c.cte;
 }
 
+// Collision check + best-path selection for E egos x P candidate paths of L points
+// (collision_checker.py:32-117 and :134-203).  One workgroup per ego; lanes stride over
+// the (path, point) pairs; the obstacle points of the ego sit in LDS and are read as
+// broadcasts; per-path collision flags, end-point scores and the argmin stay on chip.
+constexpr int kMaxPaths = 64;
+constexpr int kMaxCircles = 8;
+
+template <typename T>
+struct Circles {
+    int n;
+    T offset[kMaxCircles], radius[kMaxCircles];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *__restrict__ y,
+                        const T *__restrict__ yaw, int64_t ego_stride, int64_t path_stride, int64_t point_stride,
+                        const T *__restrict__ obst, int M, int64_t obst_ego_stride, Circles<T> circ,
+                        const T *__restrict__ goal, T weight, const int *__restrict__ collision_in,
+                        int *__restrict__ collision_free, int *__restrict__ best_idx,
+                        T *__restrict__ best_score, int chunk)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *lds_ob = reinterpret_cast<T *>(smem_raw);
+    __shared__ int s_coll[kMaxPaths];
+    __shared__ T s_ex[kMaxPaths], s_ey[kMaxPaths];
+    const int e = blockIdx.x;
+    const T *ob = obst + (int64_t)e * obst_ego_stride;
+    // collision_in given: the caller already has the flags (select_best_path_index alone)
+    if (threadIdx.x < kMaxPaths)
+        s_coll[threadIdx.x] = (collision_in != nullptr && threadIdx.x < P)
+                                  ? (collision_in[(int64_t)e * P + threadIdx.x] ? 0 : 1) : 0;
+    if (collision_in != nullptr) M = 0;
+
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int mc = min(chunk, M - m0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * mc; i += kBlock) lds_ob[i] = ob[2 * (int64_t)m0 + i];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < P * L; idx += kBlock) {
+            const int p = idx / L, j = idx - p * L;
+            const int64_t o = (int64_t)e * ego_stride + (int64_t)p * path_stride + (int64_t)j * point_stride;
+            const T px = x[o], py = y[o];
+            T sy, cy;
+            Lib<T>::sincos(yaw[o], &sy, &cy);
+            bool hit = false;
+            for (int c = 0; c < circ.n; ++c) {
+                const T cx = px + circ.offset[c] * cy;              // :88
+                const T cyy = py + circ.offset[c] * sy;             // :89
+                const T rad = circ.radius[c];
+                for (int m = 0; m < mc; ++m) {
+                    const T dx = lds_ob[2 * m] - cx, dy = lds_ob[2 * m + 1] - cyy;
+                    hit = hit || (Lib<T>::sqrt(dx * dx + dy * dy) - rad < T(0));   // :104-109
+                }
+            }
+            if (hit) atomicOr(&s_coll[p], 1);
+        }
+    }
+    __syncthreads();
+    // :134-203
+    if (threadIdx.x < P) {
+        const int64_t o = (int64_t)e * ego_stride + (int64_t)threadIdx.x * path_stride +
+                          (int64_t)(L - 1) * point_stride;
+        s_ex[threadIdx.x] = x[o];
+        s_ey[threadIdx.x] = y[o];
+        collision_free[(int64_t)e * P + threadIdx.x] = s_coll[threadIdx.x] ? 0 : 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const T gx = goal[e], gy = goal[(int64_t)E + e];
+        T bs = T(INFINITY);
+        int bi = -1;
+        for (int i = 0; i < P; ++i) {
+            T score = T(INFINITY);                                                    // :190-191
+            if (!s_coll[i]) {
+                const T ax_ = s_ex[i] - gx, ay_ = s_ey[i] - gy;
+                score = Lib<T>::sqrt(ax_ * ax_ + ay_ * ay_);                          // :175
+                for (int j = 0; j < P; ++j) {
+                    if (j == i || !s_coll[j]) continue;
+                    const T bx_ = s_ex[i] - s_ex[j], by_ = s_ey[i] - s_ey[j];
+                    score += weight * Lib<T>::sqrt(bx_ * bx_ + by_ * by_);            // :183-186
+                }
+            }
+            if (score < bs) { bs = score; bi = i; }                                   // :194-196
+        }
+        best_idx[e] = bi;
+        best_score[e] = bs;
+    }
+}
+
 // ---------------------------------------------------------------- launchers ---------
 
 template <typename T>
@@ -489,6 +579,24 @@ hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs
     return hipGetLastError();
 }
 
+template <typename T>
+hipError_t launch_select_best_path(const SelectArgs<T> &a, hipStream_t st)
+{
+    if (a.E <= 0) return hipSuccess;
+    Circles<T> c;
+    c.n = a.nc;
+    for (int i = 0; i < kMaxCircles; ++i) {
+        c.offset[i] = i < a.nc ? (T)a.offsets[i] : (T)0;
+        c.radius[i] = i < a.nc ? (T)a.radii[i] : (T)0;
+    }
+    const int chunk = std::max(1, std::min(a.M, (int)(kLdsBudget / (2 * sizeof(T)))));
+    hipLaunchKernelGGL((select_best_path_kernel<T>), dim3((unsigned)a.E), dim3(kBlock),
+                       (size_t)chunk * 2 * sizeof(T), st, a.E, a.P, a.L, a.x, a.y, a.yaw, a.ego_stride,
+                       a.path_stride, a.point_stride, a.obst, a.M, a.obst_ego_stride, c, a.goal, (T)a.weight,
+                       a.collision_in, a.collision_free, a.best_idx, a.best_score, chunk);
+    return hipGetLastError();
+}
+
 #define VDYN_INSTANTIATE(T)                                                                          \
     template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
@@ -497,7 +605,8 @@ hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs
                                              const T *, double, double, T *, int *, T *, hipStream_t); \
     template hipError_t launch_closed_loop<T>(const VdynParams &, const VdynCtrlGains &,             \
                                               const ClosedLoopArgs<T> &, hipStream_t);               \
-    template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t);
+    template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t); \
+    template hipError_t launch_select_best_path<T>(const SelectArgs<T> &, hipStream_t);
 VDYN_INSTANTIATE(float)
 VDYN_INSTANTIATE(double)
 

@@ -334,10 +334,13 @@ class VehicleModel:
         if wp.ndim != 3 or wp.shape[2] != 2 or wp.shape[1] < 1:
             raise ValueError("waypoints must be [P][Wmax][2] (x, y)")
         P, Wmax = int(wp.shape[0]), int(wp.shape[1])
-        wc = np.full(P, Wmax, dtype=np.int32) if wcount is None else np.ascontiguousarray(wcount, dtype=np.int32)
-        if wc.shape != (P,) or wc.min() < 1 or wc.max() > Wmax:
-            raise ValueError("wcount must be [P] with 1 <= wcount <= Wmax")
-        wc = be.inp(wc, int32=True)
+        if _is_torch_cuda(wcount):     # device tensor: not range-checked here, the kernel clamps to [1, Wmax]
+            wc = be.inp(wcount, shape=(P,), int32=True)
+        else:
+            wc = np.full(P, Wmax, dtype=np.int32) if wcount is None else np.ascontiguousarray(wcount, dtype=np.int32)
+            if wc.shape != (P,) or wc.min() < 1 or wc.max() > Wmax:
+                raise ValueError("wcount must be [P] with 1 <= wcount <= Wmax")
+            wc = be.inp(wc, int32=True)
         pid = be.inp(np.zeros(n, dtype=np.int32) if path_id is None else path_id, shape=(n,), int32=True)
         if not be.torch and n and (int(pid.min()) < 0 or int(pid.max()) >= P):
             raise ValueError("path_id out of range")
@@ -377,6 +380,75 @@ class VehicleModel:
             _vp(st), _vp(cs), _vp(wp), Wmax, _vp(wc), _vp(pid), P, float(self.dt if dt is None else dt),
             _vp(term), _vp(cso), _vp(lg), *be.stream_args())
         return (term, cso, lg) if log else (term, cso)
+
+    # ------------------------------------------------- collision check + best-path selection
+    def select_best_path(self, paths, obstacles, goal, circle_offsets=(-1.0, 1.0, 3.0),
+                         circle_radii=(1.5, 1.5, 1.5), weight=10.0, collision_free=None):
+        """collision_checker.py:32-117 + :134-203 for E egos x P paths x L points.
+
+        ``paths [E][P][3][L]`` (rows x, y, yaw: the reference's path lists); ``obstacles
+        [M][2]`` shared or ``[E][M][2]``; ``goal [2][E]``.  ``collision_free [E][P]`` given:
+        skip the check (select_best_path_index alone).  Returns ``collision_free [E][P]`` bool,
+        ``best_idx [E]`` (-1 = None) and ``best_score [E]``.  Defaults: drive.py:25-28."""
+        pa = np.ascontiguousarray(paths)
+        dtype = pa.dtype if pa.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+        pa = pa.astype(dtype, copy=False)
+        if pa.ndim != 4 or pa.shape[2] != 3:
+            raise ValueError("paths must be [E][P][3][L]")
+        E, P, _, L = pa.shape
+        if P > 64:
+            raise ValueError("at most 64 paths per ego")
+        ob = np.ascontiguousarray(obstacles, dtype=dtype).reshape((-1, 2) if np.ndim(obstacles) < 3 else
+                                                                  np.shape(obstacles))
+        per_ego = ob.ndim == 3
+        if ob.shape[-1] != 2 or (per_ego and ob.shape[0] != E):
+            raise ValueError("obstacles must be [M][2] or [E][M][2]")
+        M = ob.shape[-2]
+        gl = np.ascontiguousarray(goal, dtype=dtype)
+        if gl.shape != (2, E):
+            raise ValueError("goal must be [2][E]")
+        off = np.ascontiguousarray(circle_offsets, dtype=np.float64)
+        rad = np.ascontiguousarray(circle_radii, dtype=np.float64)
+        if off.shape != rad.shape or off.ndim != 1 or not 1 <= off.size <= 8:
+            raise ValueError("1..8 circle offsets / radii")
+        cin = None if collision_free is None else np.ascontiguousarray(collision_free, dtype=np.int32)
+        if cin is not None and cin.shape != (E, P):
+            raise ValueError("collision_free must be [E][P]")
+        free, bi, bs = np.empty((E, P), np.int32), np.empty(E, np.int32), np.empty(E, dtype)
+        self._handle(self.device).call(
+            f"vdyn_select_best_path_{_suffix(dtype)}_host", E, P, L, _vp(pa), _vp(ob), M, int(per_ego), _vp(off),
+            _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(free), _vp(bi), _vp(bs))
+        return free.astype(bool), bi, bs
+
+    def select_best_rollout(self, traj, paths_per_ego, obstacles, goal, circle_offsets=(-1.0, 1.0, 3.0),
+                            circle_radii=(1.5, 1.5, 1.5), weight=10.0):
+        """The same selection fed in place by the trajectory output of ``rollout`` on the GPU:
+        ``traj [L][12][N]`` (torch CUDA tensor, N = E * paths_per_ego, ego-major), obstacles
+        ``[M][2]`` and ``goal [2][E]`` tensors on the same device."""
+        be = _Backend(traj)
+        if not be.torch or traj.ndim != 3 or traj.shape[1] != 12:
+            raise ValueError("traj must be a torch CUDA tensor [L][12][N]")
+        tr = be.inp(traj)
+        L, _, N = tr.shape
+        P = int(paths_per_ego)
+        if P < 1 or P > 64 or N % P:
+            raise ValueError("N must be a multiple of paths_per_ego (<= 64)")
+        E = N // P
+        ob = be.inp(obstacles)
+        gl = be.inp(goal, shape=(2, E))
+        if ob.ndim != 2 or ob.shape[1] != 2:
+            raise ValueError("obstacles must be [M][2]")
+        off = np.ascontiguousarray(circle_offsets, dtype=np.float64)
+        rad = np.ascontiguousarray(circle_radii, dtype=np.float64)
+        free, bi, bs = be.out(E, P, int32=True), be.out(E, int32=True), be.out(E)
+        esz = tr.element_size()
+        base = tr.data_ptr()
+        row = lambda r: C.c_void_p(base + r * N * esz)
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_select_best_path_{be.suffix}_dev", E, P, int(L), row(8), row(9), row(7), P, 1, 12 * N,
+            _vp(ob), int(ob.shape[0]), 0, _vp(off), _vp(rad), int(off.size), _vp(gl), float(weight), None,
+            _vp(free), _vp(bi), _vp(bs), *be.stream_args())
+        return free, bi, bs
 
     def synchronize(self, device=None):
         """Wait for the default stream of `device` (NumPy calls are already synchronous)."""

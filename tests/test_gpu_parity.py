@@ -445,3 +445,51 @@ def test_closed_loop_batch_vs_oracle_and_properties(gpu_vm, pkg, oracle):
     # batched controller update == first controller step of the closed loop
     cu, out = vm.controller_update(s0, c0, wp, wcount=wc, path_id=pid, gains=gains)
     assert np.array_equal(out[1], log[0, 14]) and np.array_equal(cu[4], log[0, 12])
+
+
+# ---- "next" row 2: collision check + best-path selection ---------------------------------------
+def test_g10_collision_and_selection(gpu_vm, pkg, oracle):
+    """63 cases from the reference (its planner's own 3 calls + 60 obstacle re-placements):
+    collision flags and best index must match exactly; then the reference-named drop-ins."""
+    g = load_golden("g10_collision_select.npz")
+    vm = gpu_vm(1e-3)
+    args = (g["circle_offsets"], g["circle_radii"], float(g["weight"]))
+    free, bi, bs = vm.select_best_path(g["paths"], g["obstacles"], g["goal"].T.copy(), *args)
+    assert np.array_equal(free, g["collision_free"]) and np.array_equal(bi, g["best_index"])
+    _, _, obs = oracle.select_best_path(g["paths"], g["obstacles"], g["goal"].T.copy(), *args)
+    ok = bi >= 0
+    assert np.abs(bs[ok] - obs[ok]).max() <= 1e-9 and np.isinf(bs[~ok]).all()
+    f32, b32, _ = vm.select_best_path(g["paths"].astype(np.float32), g["obstacles"].astype(np.float32),
+                                      g["goal"].T.astype(np.float32), *args)
+    assert (f32 == g["collision_free"]).mean() >= 0.99       # fp32 may flip a grazing contact
+    cc = pkg.CollisionChecker(list(g["circle_offsets"]), list(g["circle_radii"]), float(g["weight"]))
+    for i in (0, 5, 17, 40):
+        flags = [cc.collision_check([list(r) for r in g["paths"][i, k]], g["obstacles"][i]) for k in range(7)]
+        assert flags == list(g["collision_free"][i])
+        best = cc.select_best_path_index(g["paths"][i], flags, list(g["goal"][i]) + [25.0])
+        assert (-1 if best is None else best) == g["best_index"][i]
+
+
+def test_rollout_trajectories_feed_selection_in_place(gpu_vm, oracle, workloads):
+    """rollout (traj) -> select_best_rollout on the GPU, against the oracle chain on the host:
+    1022 egos x 7 lattice rollouts, trajectory sampled every 10 steps, shared obstacles."""
+    import torch
+    dev = torch.device("cuda:0")
+    E, P, H = 1022, 7, 100
+    s0, tab, pid = workloads.config3(E * P, H, np.float64)
+    s0[8:10] = 0.0                                           # all egos start at the origin ...
+    s0[7] = np.repeat(np.linspace(-np.pi, np.pi, E, endpoint=False), P)   # ... heading everywhere
+    tab[:, :, 0] *= 4.0
+    vm = gpu_vm(2e-3)
+    ang = np.random.default_rng(8).uniform(-np.pi, np.pi, 14)
+    ob = np.stack([7.5 * np.cos(ang), 7.5 * np.sin(ang)], axis=1)   # 14 obstacle points on a 7.5 m circle
+    goal = np.stack([5 * np.cos(s0[7, ::P]), 5 * np.sin(s0[7, ::P])])
+    term, traj = vm.rollout(torch.from_numpy(s0).to(dev), torch.from_numpy(tab).to(dev),
+                            path_id=torch.from_numpy(pid).to(dev), traj_stride=10)
+    free, bi, bs = vm.select_best_rollout(traj, P, torch.from_numpy(ob).to(dev), torch.from_numpy(goal).to(dev))
+    tr = traj.cpu().numpy()                                   # [L][12][N] -> paths [E][P][3][L]
+    paths = np.transpose(tr[:, [8, 9, 7], :], (2, 1, 0)).reshape(E, P, 3, -1)
+    of, obi, obs = oracle.select_best_path(paths, ob, goal, nthreads=8)
+    assert np.array_equal(free.cpu().numpy().astype(bool), of)
+    assert np.array_equal(bi.cpu().numpy(), obi)
+    assert 0.05 < of.mean() < 0.95, "the case must mix colliding and free paths"
