@@ -54,10 +54,14 @@ __device__ __forceinline__ T wrap_pi(T e)
     return m - pi;
 }
 
-// Waypoint access: a table of (x, y) pairs, either staged in LDS or read through L2.
+// Waypoint access: a table of (x, y) pairs, either staged in LDS or read through L2, and
+// (optionally) the table of segment lengths seg[i] = |wp[i] - wp[i-1]| (seg[0] unused) that
+// the workgroup computed once, so that the lookahead walk does not take a sqrt per lane
+// per waypoint.
 template <typename T>
 struct Waypoints {
     const T *base;  // this lane's table: [W][2]
+    const T *seg;   // nullable: [W] segment lengths of the same table
     int W;
     __device__ __forceinline__ void get(int i, T &x, T &y) const
     {
@@ -66,15 +70,27 @@ struct Waypoints {
     }
 };
 
-// stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
 template <typename T>
-__device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Waypoints<T> &wp, T x, T y, T yaw,
-                                                T v, T &steer_out, int &idx_out, T &cte_out)
+__device__ __forceinline__ T segment_length(T ax, T ay, T bx, T by)
+{
+    const T ex = bx - ax, ey = by - ay;
+    return Lib<T>::sqrt(ex * ex + ey * ey);
+}
+
+// stanley_controller.py:56-66: global nearest waypoint, first minimum under strict '<' of
+// the sqrt distances.  EXACT = false compares squared distances only (branch-free, so the
+// loop unrolls and its LDS reads pipeline) and reports through `ambiguous` whether some
+// candidate came so close to the running minimum that the rounded roots might have tied;
+// EXACT = true settles every such candidate with the roots themselves.
+template <typename T, bool EXACT>
+__device__ __forceinline__ void nearest_waypoint(const Waypoints<T> &wp, T x, T y, T &best_d2, int &best_i,
+                                                 bool &ambiguous)
 {
     using L = Lib<T>;
-    // :56-66 global nearest waypoint, first minimum under strict '<' of the sqrt distances
-    T best_d2 = T(INFINITY);
-    int best_i = 0;
+    best_d2 = T(INFINITY);
+    best_i = 0;
+    ambiguous = false;
+#pragma unroll 8
     for (int i = 0; i < wp.W; ++i) {
         T wx, wy;
         wp.get(i, wx, wy);
@@ -82,28 +98,64 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
         const T d2 = dx * dx + dy * dy;
         bool better = d2 < best_d2;
         // sqrt is monotone, so d2 < best_d2 implies sqrt(d2) <= sqrt(best_d2); equality of the
-        // rounded roots (the reference would then keep the earlier index) is only possible
-        // within a few ulp -- settle exactly that case with the roots themselves
-        if (__builtin_expect(__any(better && d2 >= best_d2 * L::kTieBand) != 0, 0)) {
-            if (better && d2 >= best_d2 * L::kTieBand) better = L::sqrt(d2) < L::sqrt(best_d2);
+        // rounded roots (the reference would then keep the earlier index) needs d2 within a
+        // few ulp of best_d2
+        const bool close = better && d2 >= best_d2 * L::kTieBand;
+        if (EXACT) {
+            if (close) better = L::sqrt(d2) < L::sqrt(best_d2);
+        } else {
+            ambiguous = ambiguous || close;
         }
         best_d2 = better ? d2 : best_d2;
         best_i = better ? i : best_i;
+    }
+}
+
+// stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
+template <typename T>
+__device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Waypoints<T> &wp, T x, T y, T yaw,
+                                                T v, T &steer_out, int &idx_out, T &cte_out)
+{
+    using L = Lib<T>;
+    T best_d2;
+    int best_i;
+    bool amb;
+    nearest_waypoint<T, false>(wp, x, y, best_d2, best_i, amb);
+    if (__builtin_expect(__any(amb) != 0, 0)) {          // wave-uniform, practically never taken
+        if (amb) nearest_waypoint<T, true>(wp, x, y, best_d2, best_i, amb);
     }
     // :68-76 walk forward until the accumulated arc length reaches the lookahead distance
     T total = L::sqrt(best_d2);
     int ce = best_i;
     T px, py;
     wp.get(best_i, px, py);
-    for (int i = best_i + 1; i < wp.W; ++i) {
-        if (total >= G.lookahead) break;
-        T qx, qy;
-        wp.get(i, qx, qy);
-        const T ex = qx - px, ey = qy - py;
-        total += L::sqrt(ex * ex + ey * ey);
-        ce = i;
-        px = qx;
-        py = qy;
+    if (wp.seg != nullptr) {
+        // same sequential sum as the reference, eight precomputed segment lengths per trip:
+        // the reads go out together and the early exit becomes a per-lane predicate
+        bool done = total >= G.lookahead;
+        for (int i0 = best_i + 1; i0 < wp.W && !done; i0 += 8) {
+            T sg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sg[k] = wp.seg[min(i0 + k, wp.W - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool take = !done && (i0 + k) < wp.W;
+                total = take ? total + sg[k] : total;
+                ce = take ? i0 + k : ce;
+                done = done || !take || total >= G.lookahead;
+            }
+        }
+        wp.get(ce, px, py);
+    } else {
+        for (int i = best_i + 1; i < wp.W; ++i) {
+            if (total >= G.lookahead) break;
+            T qx, qy;
+            wp.get(i, qx, qy);
+            total += segment_length<T>(px, py, qx, qy);
+            ce = i;
+            px = qx;
+            py = qy;
+        }
     }
     // :90-98 (px, py) is waypoint ce
     T sy, cy;

@@ -232,10 +232,21 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
                    T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    // LDS image: P tables of (x, y) pairs, then P tables of segment lengths; each table is
+    // padded by one entry so that the tables of different paths start on different banks
+    // (lanes of one wave follow different paths and read the same waypoint index together)
+    const int wstride = Wmax + 1;
     T *lds_wp = reinterpret_cast<T *>(smem_raw);
+    T *lds_seg = lds_wp + (int64_t)Pn * wstride * 2;
     if (WPLDS) {
-        const int total = Pn * Wmax * 2;
-        for (int i = threadIdx.x; i < total; i += kBlock) lds_wp[i] = wp[i];
+        for (int i = threadIdx.x; i < Pn * Wmax; i += kBlock) {
+            const int p = i / Wmax, j = i - p * Wmax;
+            const T wx = wp[2 * (int64_t)i], wy = wp[2 * (int64_t)i + 1];
+            lds_wp[2 * (p * wstride + j)] = wx;
+            lds_wp[2 * (p * wstride + j) + 1] = wy;
+            // segment lengths, once per workgroup instead of once per lane per walk step
+            lds_seg[p * wstride + j] = j == 0 ? T(0) : segment_length<T>(wp[2 * (int64_t)i - 2], wp[2 * (int64_t)i - 1], wx, wy);
+        }
         __syncthreads();
     }
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -259,7 +270,8 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
 
     const int pid = min(max(path_id[r], 0), Pn - 1);
     Waypoints<T> w;
-    w.base = (WPLDS ? lds_wp : wp) + (int64_t)pid * Wmax * 2;
+    w.base = WPLDS ? lds_wp + (int64_t)pid * wstride * 2 : wp + (int64_t)pid * Wmax * 2;
+    w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : nullptr;
     w.W = min(max(wcount[pid], 1), Wmax);
 
     for (int t = 0; t < H; ++t) {
@@ -320,6 +332,7 @@ controller_kernel(CtrlGains<T> G, int64_t n, const T *__restrict__ state, const 
     const int pid = min(max(path_id[r], 0), Pn - 1);
     Waypoints<T> w;
     w.base = wp + (int64_t)pid * Wmax * 2;
+    w.seg = nullptr;
     w.W = min(max(wcount[pid], 1), Wmax);
     T steer;
     controller_update<T>(G, w, s, h, c, steer);
@@ -553,17 +566,24 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
     const CtrlGains<T> G = make_gains<T>(g);
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
-    const size_t wp_bytes = (size_t)a.P * a.Wmax * 2 * sizeof(T);
-    const bool lds = wp_bytes <= 64 * 1024;
+    const size_t wp_bytes = (size_t)a.P * (a.Wmax + 1) * 3 * sizeof(T);   // padded (x, y) pairs + segment lengths
+    // gfx950 has 160 KiB of LDS per CU; a workgroup may take all of it (one workgroup per
+    // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
+    const bool lds = wp_bytes <= 152 * 1024;
     const bool cs = shape_factors_small(p);
 #define VDYN_CL(CSV, LDSV)                                                                            \
+    if (LDSV && wp_bytes > 64 * 1024) {                                                               \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wp_bytes); \
+        if (e_ != hipSuccess) return e_;                                                              \
+    }                                                                                                 \
     hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV>), dim3(grid), dim3(kBlock), LDSV ? wp_bytes : 0, \
                        st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0, a.cstate0, a.wp, a.Wmax,   \
                        a.wcount, a.path_id, a.P, (T)a.dt, a.terminal, a.cstate, a.log)
-    if (cs && lds) VDYN_CL(true, true);
-    else if (cs) VDYN_CL(true, false);
-    else if (lds) VDYN_CL(false, true);
-    else VDYN_CL(false, false);
+    if (cs && lds) { VDYN_CL(true, true); }
+    else if (cs) { VDYN_CL(true, false); }
+    else if (lds) { VDYN_CL(false, true); }
+    else { VDYN_CL(false, false); }
 #undef VDYN_CL
     return hipGetLastError();
 }
