@@ -102,15 +102,15 @@ def cpu_baseline(W):
     }
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
-    (profiles/pmc_summary.json, written by profiles/collect.sh), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+def pmc_summary():
+    """The committed rocprofv3 --pmc summary of this very command (profiles/pmc_summary.json,
+    written by profiles/collect.sh + summarize.py): HBM bytes per launch and VALU
+    wave-instructions per RK4 step of the rollout kernel.  {} when absent."""
     try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def main():
@@ -193,11 +193,12 @@ def main():
         },
     }
     if rank == 0:
+        pmc = pmc_summary()
         algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * N_PER_GPU
         ach = algo_bytes / kern_s / 1e9
         out["roofline"] = {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
             "kernel": "rollout_kernel<float,2,LDS-shared>", "kernel_ms": kern_s * 1e3,
             "algorithmic_bytes_per_launch": algo_bytes,
             "note": "register-resident scalar-nonlinear kernel: HBM and MFMA are both idle by design; "
@@ -209,6 +210,17 @@ def main():
             "frac": tf / VALU_PEAK_TFLOPS, "flop_per_vehicle_step": FLOP_PER_STEP,
             "kernel_steps_per_s": steps_per_launch / kern_s,
         }
+        ipw = pmc.get("valu_insts_per_wave_per_rk4_step")
+        if ipw:
+            # issue-slot form of the same roofline: measured VALU wave-instructions per RK4 step
+            # (SQ_INSTS_VALU / SQ_WAVES / H) x wave-steps per second, against 1024 SIMDs issuing
+            # one wave64 VALU instruction per 2 cycles at 2.4 GHz; a lone wave per SIMD (what
+            # 65536 rollouts give) cannot issue faster than one per 4 cycles = 0.5 of that peak
+            issue = ipw * (steps_per_launch / 64.0) / kern_s
+            peak_issue = 1024 * 2.4e9 / 2
+            out["roofline_valu"].update({
+                "valu_insts_per_wave_step": ipw, "issue_rate": issue, "issue_peak": peak_issue,
+                "issue_frac": issue / peak_issue, "issue_frac_of_one_wave_per_simd_ceiling": issue / (peak_issue / 2)})
         if world == 1 and not args.no_extra:
             out["extra"] = extra_configs(vm, W, torch, dev, s0, tab, pid)
         if world == 1 and not args.no_cpu_baseline:
