@@ -212,23 +212,28 @@ int vdyn_controller_update_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64
  * their commands in between; every sub-step is the RK4 step of vdyn_step_* with
  * delta=[d,d,0,0], torques=[t,t,t,t], mu_max=[1,1,1,1] (drive.py:141-143).
  * -> terminal [12][n], cstate_out [6][n], log (nullable) [H][16][n] with rows state12, delta,
- *    torque, target index, crosstrack error: the per-step content of drive.py:145-151.       */
+ *    torque, target index, crosstrack error; datalog (nullable) [H][45][n] = the 45 columns
+ *    the reference writes into Car.DataLog per sub-step (drive.py:145-151, names
+ *    plots.py:19-27): t = (phase + step) * dt, state x10, state_dot x10, delta, torque x4,
+ *    outputs x18, crosstrack error.                                                           */
 int vdyn_closed_loop_f64_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
                              int32_t phase, const double *state0, const double *cstate_in, const double *wp,
                              int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
-                             double dt, double *terminal, double *cstate_out, double *log, void *stream);
+                             double dt, double *terminal, double *cstate_out, double *log, double *datalog,
+                             void *stream);
 int vdyn_closed_loop_f32_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
                              int32_t phase, const float *state0, const float *cstate_in, const float *wp,
                              int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
-                             double dt, float *terminal, float *cstate_out, float *log, void *stream);
+                             double dt, float *terminal, float *cstate_out, float *log, float *datalog,
+                             void *stream);
 int vdyn_closed_loop_f64_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
                               int32_t phase, const double *state0, const double *cstate_in, const double *wp,
                               int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
-                              double dt, double *terminal, double *cstate_out, double *log);
+                              double dt, double *terminal, double *cstate_out, double *log, double *datalog);
 int vdyn_closed_loop_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
                               int32_t phase, const float *state0, const float *cstate_in, const float *wp,
                               int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,
-                              double dt, float *terminal, float *cstate_out, float *log);
+                              double dt, float *terminal, float *cstate_out, float *log, float *datalog);
 
 /* ==== "next" row: collision check + best-path selection ===================================
  * Replaces: CollisionChecker.collision_check (collision_checker.py:32-117, one call per path;

@@ -72,7 +72,7 @@ for _s in ("f32", "f64"):
     _cu = [_vp, _gp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp]
     SIGNATURES[f"vdyn_controller_update_{_s}_dev"] = (_int, _cu + [_vp])
     SIGNATURES[f"vdyn_controller_update_{_s}_host"] = (_int, _cu)
-    _cl = [_vp, _gp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp, _vp]
+    _cl = [_vp, _gp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp, _vp, _vp]
     SIGNATURES[f"vdyn_closed_loop_{_s}_dev"] = (_int, _cl + [_vp])
     SIGNATURES[f"vdyn_closed_loop_{_s}_host"] = (_int, _cl)
 

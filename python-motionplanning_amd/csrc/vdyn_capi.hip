@@ -411,7 +411,8 @@ int closed_loop_host(VdynHandle *h, const VdynCtrlGains *g, vdyn::ClosedLoopArgs
                  i2 = s.in(a.wp, sizeof(T) * (size_t)a.P * a.Wmax * 2),
                  i3 = s.in(a.wcount, sizeof(int32_t) * (size_t)a.P), i4 = s.in(a.path_id, sizeof(int32_t) * (size_t)a.n);
     const size_t o0 = s.out(a.terminal, 12 * e), o1 = s.out(a.cstate, 6 * e),
-                 o2 = s.out(a.log, a.log ? (size_t)a.H * 16 * e : 0), o3 = s.out(a.ctrl_out, 3 * e);
+                 o2 = s.out(a.log, a.log ? (size_t)a.H * 16 * e : 0), o3 = s.out(a.ctrl_out, 3 * e),
+                 o4 = s.out(a.datalog, a.datalog ? (size_t)a.H * 45 * e : 0);
     rc = s.upload();
     if (rc) return rc;
     a.state0 = s.dev<T>(i0, false);
@@ -423,6 +424,7 @@ int closed_loop_host(VdynHandle *h, const VdynCtrlGains *g, vdyn::ClosedLoopArgs
     a.cstate = s.dev<T>(o1, true);
     a.log = s.dev<T>(o2, true);
     a.ctrl_out = s.dev<T>(o3, true);
+    a.datalog = s.dev<T>(o4, true);
     rc = closed_loop_dev<T>(h, g, a, update_only, h->stream);
     if (rc) return rc;
     return s.download();
@@ -432,12 +434,12 @@ template <typename T>
 vdyn::ClosedLoopArgs<T> cl_args(int64_t n, int32_t H, int32_t ctrl_every, int32_t phase, const T *state0,
                                 const T *cstate_in, const T *wp, int32_t Wmax, const int32_t *wcount,
                                 const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log,
-                                T *ctrl_out)
+                                T *ctrl_out, T *datalog = nullptr)
 {
     vdyn::ClosedLoopArgs<T> a;
     a.n = n; a.H = H; a.ctrl_every = ctrl_every; a.phase = phase; a.state0 = state0; a.cstate0 = cstate_in;
     a.wp = wp; a.Wmax = Wmax; a.wcount = wcount; a.path_id = path_id; a.P = P; a.dt = dt;
-    a.terminal = terminal; a.cstate = cstate_out; a.log = log; a.ctrl_out = ctrl_out;
+    a.terminal = terminal; a.cstate = cstate_out; a.log = log; a.ctrl_out = ctrl_out; a.datalog = datalog;
     return a;
 }
 
@@ -597,20 +599,21 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
     extern "C" int vdyn_closed_loop_##S##_dev(                                                           \
         VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every, int32_t phase,  \
         const T *state0, const T *cstate_in, const T *wp, int32_t Wmax, const int32_t *wcount,           \
-        const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log, void *stream)  \
+        const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log, T *datalog,    \
+        void *stream)                                                                                    \
     {                                                                                                    \
         return closed_loop_dev<T>(h, g, cl_args<T>(n, H, ctrl_every, phase, state0, cstate_in, wp, Wmax, wcount, \
-                                                   path_id, P, dt, terminal, cstate_out, log, nullptr),  \
-                                  false, stream);                                                        \
+                                                   path_id, P, dt, terminal, cstate_out, log, nullptr,   \
+                                                   datalog), false, stream);                             \
     }                                                                                                    \
     extern "C" int vdyn_closed_loop_##S##_host(                                                          \
         VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every, int32_t phase,  \
         const T *state0, const T *cstate_in, const T *wp, int32_t Wmax, const int32_t *wcount,           \
-        const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log)                \
+        const int32_t *path_id, int32_t P, double dt, T *terminal, T *cstate_out, T *log, T *datalog)    \
     {                                                                                                    \
         return closed_loop_host<T>(h, g, cl_args<T>(n, H, ctrl_every, phase, state0, cstate_in, wp, Wmax, wcount, \
-                                                    path_id, P, dt, terminal, cstate_out, log, nullptr), \
-                                   false);                                                               \
+                                                    path_id, P, dt, terminal, cstate_out, log, nullptr,  \
+                                                    datalog), false);                                    \
     }
 
 #define VDYN_DEFINE_SELECT_ABI(S, T)                                                                     \

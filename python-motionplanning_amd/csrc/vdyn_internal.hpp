@@ -57,6 +57,7 @@ struct ClosedLoopArgs {
     T *terminal = nullptr;        // [12][n]
     T *cstate = nullptr;          // [6][n]
     T *log = nullptr;             // nullable [H][16][n]
+    T *datalog = nullptr;         // nullable [H][45][n]: the reference's DataLog columns
     T *ctrl_out = nullptr;        // controller_update only: [3][n]
 };
 

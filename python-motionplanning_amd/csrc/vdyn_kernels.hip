@@ -224,12 +224,16 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
 //   WPLDS: all P waypoint tables fit the LDS budget and are staged there once per workgroup;
 //          otherwise the scan reads them through L2.
 //   log (nullable): [H][16][n] rows state12, delta, torque, target index, crosstrack error.
-template <typename T, bool CS, bool WPLDS>
+//   DATALOG: datalog [H][45][n] = the 45 columns Car.DataLog receives per sub-step
+//            (drive.py:145-151; names in plots.py:19-27): t, state x10, state_dot x10, delta,
+//            torque x4, outputs x18, crosstrack error.
+template <typename T, bool CS, bool WPLDS, bool DATALOG>
 __global__ void __launch_bounds__(kBlock)
 closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_every, int phase,
                    const T *__restrict__ state0, const T *__restrict__ cstate0, const T *__restrict__ wp,
                    int Wmax, const int *__restrict__ wcount, const int *__restrict__ path_id, int Pn, T h,
-                   T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log)
+                   T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log,
+                   T *__restrict__ datalog)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS image: P tables of (x, y) pairs, then P tables of segment lengths; each table is
@@ -281,7 +285,23 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         }
         const T delta[4] = {c.delta, c.delta, T(0), T(0)};
         const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
-        rk4_advance<T, true, false, CS>(P, s, ax, ay, delta, tq, P.mu, h, nullptr, nullptr);
+        T sd[10];
+        Outputs18<T> o18;
+        rk4_advance<T, true, DATALOG, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, &o18);
+        if (DATALOG && active) {
+            T *row = datalog + (int64_t)t * 45 * n + r;
+            row[0] = (T)(phase + t) * h;                                          // drive.py:145
+#pragma unroll
+            for (int i = 0; i < 10; ++i) row[(int64_t)(1 + i) * n] = s[i];       // :146
+#pragma unroll
+            for (int i = 0; i < 10; ++i) row[(int64_t)(11 + i) * n] = sd[i];     // :147
+            row[(int64_t)21 * n] = c.delta;                                       // :148
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row[(int64_t)(22 + i) * n] = c.tau;      // :149
+#pragma unroll
+            for (int i = 0; i < 18; ++i) row[(int64_t)(26 + i) * n] = o18.v[i];  // :150
+            row[(int64_t)44 * n] = c.cte;                                         // :151
+        }
         if (log != nullptr && active) {
             T *row = log + (int64_t)t * 16 * n + r;
 #pragma unroll
@@ -571,19 +591,26 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
     const bool lds = wp_bytes <= 152 * 1024;
     const bool cs = shape_factors_small(p);
+#define VDYN_CL2(CSV, LDSV, DLV)                                                                      \
+    {                                                                                                 \
+        if (LDSV && wp_bytes > 64 * 1024) {                                                           \
+            hipError_t e_ = hipFuncSetAttribute(                                                      \
+                reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV, DLV>),               \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wp_bytes);                           \
+            if (e_ != hipSuccess) return e_;                                                          \
+        }                                                                                             \
+        hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV>), dim3(grid), dim3(kBlock),         \
+                           LDSV ? wp_bytes : 0, st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0,  \
+                           a.cstate0, a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.terminal,    \
+                           a.cstate, a.log, a.datalog);                                               \
+    }
 #define VDYN_CL(CSV, LDSV)                                                                            \
-    if (LDSV && wp_bytes > 64 * 1024) {                                                               \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV>), \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wp_bytes); \
-        if (e_ != hipSuccess) return e_;                                                              \
-    }                                                                                                 \
-    hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV>), dim3(grid), dim3(kBlock), LDSV ? wp_bytes : 0, \
-                       st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0, a.cstate0, a.wp, a.Wmax,   \
-                       a.wcount, a.path_id, a.P, (T)a.dt, a.terminal, a.cstate, a.log)
-    if (cs && lds) { VDYN_CL(true, true); }
-    else if (cs) { VDYN_CL(true, false); }
-    else if (lds) { VDYN_CL(false, true); }
-    else { VDYN_CL(false, false); }
+    if (a.datalog != nullptr) VDYN_CL2(CSV, LDSV, true) else VDYN_CL2(CSV, LDSV, false)
+    if (cs && lds) { VDYN_CL(true, true) }
+    else if (cs) { VDYN_CL(true, false) }
+    else if (lds) { VDYN_CL(false, true) }
+    else { VDYN_CL(false, false) }
+#undef VDYN_CL2
 #undef VDYN_CL
     return hipGetLastError();
 }

@@ -363,11 +363,12 @@ class VehicleModel:
         return cso, out
 
     def closed_loop(self, states0, cstate0, waypoints, H, wcount=None, path_id=None, gains=None, dt=None,
-                    ctrl_every=10, phase=0, log=False):
+                    ctrl_every=10, phase=0, log=False, datalog=False):
         """H sub-steps of the reference's Car.drive loop (drive.py:114-151) minus the planner:
         controllers every ``ctrl_every`` steps (zero-order hold), RK4 every step.
         Returns ``terminal [12][N]``, ``cstate [6][N]`` (and ``log [H][16][N]``: state12, delta,
-        torque, target index, crosstrack error)."""
+        torque, target index, crosstrack error; and/or ``datalog [H][45][N]``: the reference's
+        DataLog columns, drive.py:145-151 / plots.py:19-27, with t = (phase + step) * dt)."""
         be = _Backend(states0)
         st, n, cs, wp, P, Wmax, wc, pid = self._closed_loop_inputs(be, states0, cstate0, waypoints, wcount, path_id)
         if H < 0 or ctrl_every <= 0 or phase < 0:
@@ -375,11 +376,12 @@ class VehicleModel:
         g = gains if gains is not None else _lib.default_ctrl_gains()
         term, cso = be.out(12, n), be.out(6, n)
         lg = be.out(int(H), 16, n) if log else None
+        dl = be.out(int(H), 45, n) if datalog else None
         self._handle(be.device_index(self.device)).call(
             f"vdyn_closed_loop_{be.suffix}_{be.kind}", C.byref(g), n, int(H), int(ctrl_every), int(phase),
             _vp(st), _vp(cs), _vp(wp), Wmax, _vp(wc), _vp(pid), P, float(self.dt if dt is None else dt),
-            _vp(term), _vp(cso), _vp(lg), *be.stream_args())
-        return (term, cso, lg) if log else (term, cso)
+            _vp(term), _vp(cso), _vp(lg), _vp(dl), *be.stream_args())
+        return (term, cso) + ((lg,) if log else ()) + ((dl,) if datalog else ())
 
     # ------------------------------------------------- collision check + best-path selection
     def select_best_path(self, paths, obstacles, goal, circle_offsets=(-1.0, 1.0, 3.0),

@@ -493,3 +493,46 @@ def test_rollout_trajectories_feed_selection_in_place(gpu_vm, oracle, workloads)
     assert np.array_equal(free.cpu().numpy().astype(bool), of)
     assert np.array_equal(bi.cpu().numpy(), obi)
     assert 0.05 < of.mean() < 0.95, "the case must mix colliding and free paths"
+
+
+# ---- "next" row 4: the DataLog wire format -------------------------------------------------------
+def test_datalog_matches_reference_log(gpu_vm, pkg):
+    """The 45 columns the reference's Car.drive wrote into Car.DataLog for 300 sub-steps
+    (drive.py:145-151, G4) against the closed-loop kernel's datalog output, frame by frame."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    ref = load_golden("g4_closed_loop_world.npz")["datalog"]                    # [300][45]
+    dt = float(g["dt"])
+    vm = gpu_vm(dt)
+    gains = _g9_gains(pkg, g)
+    s = np.concatenate([g["state"], g["ax_ay_prev"]])[:, None]
+    c = np.array([g["x_del"], g["total_vel_error"], g["prev_vel"], g["target_vel"], 0.0, 0.0])[:, None]
+    rows = []
+    for f in range(3):
+        wp = g["waypoints"][f, :g["waypoint_count"][f], :2]
+        s, c, dl = vm.closed_loop(s, c, wp, 100, gains=gains, phase=100 * f, datalog=True)
+        assert dl.shape == (100, 45, 1)
+        rows.append(dl[:, :, 0])
+    got = np.concatenate(rows)
+    scale = np.maximum(np.abs(ref).max(axis=0), 1e-6)
+    err = np.abs(got - ref) / scale
+    assert err[:, 0].max() <= 1e-12                       # t
+    assert err[:, 1:11].max() <= 1e-9                     # state
+    assert err[:, 11:21].max() <= 1e-7                    # state_dot (forces / m: cancellation-limited)
+    assert err[:, 21:26].max() <= 1e-9                    # delta, torque x4
+    assert err[:, 26:44].max() <= 1e-9                    # outputs
+    assert err[:, 44].max() <= 1e-9                       # crosstrack error
+    # fp32, through torch tensors on the device
+    import torch
+    dev = torch.device("cuda:0")
+    s32 = torch.from_numpy(np.concatenate([g["state"], g["ax_ay_prev"]])[:, None].astype(np.float32)).to(dev)
+    c32 = torch.tensor([[float(g["x_del"])], [0.0], [float(g["prev_vel"])], [float(g["target_vel"])], [0.0],
+                        [0.0]], dtype=torch.float32, device=dev)
+    wp32 = torch.from_numpy(g["waypoints"][0, :g["waypoint_count"][0], :2].astype(np.float32)).to(dev)
+    _, _, dl32 = vm.closed_loop(s32, c32, wp32, 100, gains=gains, datalog=True)
+    d32 = np.abs(dl32.cpu().numpy()[:, :, 0] - ref[:100])
+    assert (d32[:, 1:11] / np.maximum(np.abs(ref[:100, 1:11]).max(axis=0), 1.0)).max() <= 1e-3
+    # on this straight the tire forces are a few newtons out of slips of 1e-5, i.e. differences of
+    # fp32 speeds: judge every force column against the normal load, slips absolutely
+    fz = np.abs(ref[:100, 34:38]).max()
+    assert d32[:, 26:34].max() <= 1e-3 * fz and d32[:, 42:44].max() <= 1e-3 * fz        # Fx, Fy, FxtFL, FytFL
+    assert (d32[:, 34:38] / fz).max() <= 1e-3 and d32[:, 38:42].max() <= 1e-5           # Fz, combined slips
