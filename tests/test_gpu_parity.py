@@ -536,3 +536,29 @@ def test_datalog_matches_reference_log(gpu_vm, pkg):
     fz = np.abs(ref[:100, 34:38]).max()
     assert d32[:, 26:34].max() <= 1e-3 * fz and d32[:, 42:44].max() <= 1e-3 * fz        # Fx, Fy, FxtFL, FytFL
     assert (d32[:, 34:38] / fz).max() <= 1e-3 and d32[:, 38:42].max() <= 1e-5           # Fz, combined slips
+
+
+def test_safe_path_lanes_beyond_fast_range(gpu_vm, oracle, workloads):
+    """Lanes outside the validated range of the straight-line FAST step (|yaw| > 2^16 rad in
+    fp32 / 2^30 in fp64, |delta| > 2^16, a stage yaw increment > pi/4) are re-integrated by the
+    SAFE step; their neighbours in the same wave must be untouched bit for bit."""
+    n, H, dt = 192, 12, 1e-3
+    s0, ctrl = workloads.config2(14, H)
+    s0, ctrl = s0[:, :n].copy(), ctrl[:, :, :n].copy()
+    p = oracle.default_params()
+    clean64 = gpu_vm(dt).rollout(s0, ctrl)
+    clean32 = gpu_vm(dt).rollout(s0.astype(np.float32), ctrl.astype(np.float32))
+    big = [3, 70, 130]
+    s0[7, big] = [1.0e6, -3.0e9, 2.5e5]                 # unwrapped yaw far beyond the fast reduction
+    ctrl[:, 0, 77] += 2 * np.pi * 20000                 # a steering angle 20000 turns away
+    s0[2, 101] = 900.0                                  # yaw rate 900 rad/s: stage increment 0.9 rad
+    keep = np.setdiff1d(np.arange(n), big + [77, 101])
+    for dtype, clean, tol in ((np.float64, clean64, F64_TOL), (np.float32, clean32, F32_TOL)):
+        got = gpu_vm(dt).rollout(s0.astype(dtype), ctrl.astype(dtype))
+        assert np.array_equal(got[:, keep], clean[:, keep])
+        want = oracle.rollout(p, s0.astype(dtype).astype(np.float64), ctrl.astype(dtype).astype(np.float64), dt)
+        # yaw itself is huge: compare its sin/cos-relevant part through x, y and the other rows
+        rows = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11]
+        lanes = big + [77] if dtype == np.float64 else [3, 130, 77]     # fp32 cannot hold yaw = 3e9 + small
+        assert parity(got[rows][:, lanes], want[rows][:, lanes], tol * 50, "safe-path lanes") >= 0
+        assert np.isfinite(got[:, 101]).all()
