@@ -266,6 +266,20 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     ex["closed_loop_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3,
                                        "controller_updates_per_s": n / 10 / t, "waypoints_per_table": 1024}
     del cl
+    # BASELINE configs[0]: the reference's own call pattern -- ONE vehicle, one planar_model_RK4
+    # call per sub-step through the reference-signature drop-in (host lists in, 9-value list out)
+    vm1 = type(vm)(2.906, np.deg2rad(30), 1e-4, device=vm.device)
+    pp = vm1.params
+    st, axp, ayp = [25.0, 0, 0] + [25.0 / pp.rw] * 4 + [0, 0, 0], 0.0, 0.0
+    for _ in range(20):
+        o = vm1.planar_model_RK4(st, [50.0] * 4, [1.0] * 4, [0.02, 0.02, 0, 0], pp, axp, ayp)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        o = vm1.planar_model_RK4(st, [50.0] * 4, [1.0] * 4, [0.02, 0.02, 0, 0], pp, axp, ayp)
+        st, axp, ayp = o[0], o[7], o[8]
+    t = (time.perf_counter() - t0) / 300
+    ex["dropin_single_vehicle_step_f64"] = {"us_per_call": t * 1e6, "steps_per_s": 1.0 / t,
+                                            "reference_numpy_us_per_call": 247.7}
     # the same workload through the HOST-pointer ABI (staging copies over PCIe included)
     s0_h, pid_h = s0.cpu().numpy(), pid.cpu().numpy()
     vm.rollout(s0_h, tab, path_id=pid_h)
