@@ -141,10 +141,11 @@ class Handle:
         self.device = int(device)
         self._key = params.key()
 
-    def set_params(self, params: VdynParams):
-        if params.key() != self._key:
+    def set_params(self, params: VdynParams, key=None):
+        key = params.key() if key is None else key
+        if key != self._key:
             self.check(self._lib.vdyn_set_params(self._h, C.byref(params)))
-            self._key = params.key()
+            self._key = key
 
     def check(self, rc):
         if rc != VDYN_OK:

@@ -19,6 +19,8 @@ struct VdynHandle {
     size_t d_bytes = 0;
     void *h_pinned = nullptr;
     size_t h_bytes = 0;
+    void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
+    void *d_mapped = nullptr;       // its device address
 
     int fail(int code, const std::string &msg)
     {
@@ -153,6 +155,7 @@ void vdyn_destroy(VdynHandle *h)
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->h_mapped) (void)hipHostFree(h->h_mapped);
     delete h;
 }
 
@@ -233,6 +236,11 @@ public:
     size_t in(const void *src, size_t bytes) { return add(ins_, const_cast<void *>(src), bytes); }
     size_t out(void *dst, size_t bytes) { return add(outs_, dst, bytes); }
 
+    // Calls this small (the single-vehicle drop-ins of drive.py:141-143) skip both DMA copies:
+    // the kernel reads its inputs from, and writes its outputs to, a host-coherent mapped
+    // buffer across PCIe, so a call costs one launch and one stream synchronise.
+    static constexpr size_t kMappedBytes = 64 * 1024;
+
     int upload()
     {
         in_end_ = 0;
@@ -242,6 +250,18 @@ public:
         for (auto &r : outs_) { r.off = off; off += round(r.bytes); }
         total_ = off;
         VDYN_HIP(h_, hipSetDevice(h_->device));
+        mapped_ = total_ <= kMappedBytes;
+        if (mapped_) {
+            if (!h_->h_mapped) {
+                if (hipHostMalloc(&h_->h_mapped, kMappedBytes, hipHostMallocMapped) != hipSuccess)
+                    return h_->fail(VDYN_ERR_OOM, "mapped staging allocation failed");
+                VDYN_HIP(h_, hipHostGetDevicePointer(&h_->d_mapped, h_->h_mapped, 0));
+            }
+            host_ = (char *)h_->h_mapped;
+            dev_ = (char *)h_->d_mapped;
+            for (auto &r : ins_) std::memcpy(host_ + r.off, r.ptr, r.bytes);
+            return VDYN_OK;
+        }
         if (total_ > h_->d_bytes) {
             if (h_->d_scratch) { (void)hipFree(h_->d_scratch); h_->d_scratch = nullptr; h_->d_bytes = 0; }
             if (hipMalloc(&h_->d_scratch, total_) != hipSuccess) return h_->fail(VDYN_ERR_OOM, "device scratch allocation failed");
@@ -253,24 +273,26 @@ public:
                 return h_->fail(VDYN_ERR_OOM, "pinned staging allocation failed");
             h_->h_bytes = total_;
         }
-        for (auto &r : ins_) std::memcpy((char *)h_->h_pinned + r.off, r.ptr, r.bytes);
+        host_ = (char *)h_->h_pinned;
+        dev_ = (char *)h_->d_scratch;
+        for (auto &r : ins_) std::memcpy(host_ + r.off, r.ptr, r.bytes);
         if (in_end_ > 0)
-            VDYN_HIP(h_, hipMemcpyAsync(h_->d_scratch, h_->h_pinned, in_end_, hipMemcpyHostToDevice, h_->stream));
+            VDYN_HIP(h_, hipMemcpyAsync(dev_, host_, in_end_, hipMemcpyHostToDevice, h_->stream));
         return VDYN_OK;
     }
     template <typename T> T *dev(size_t idx, bool is_out) const
     {
         const auto &r = (is_out ? outs_ : ins_)[idx];
-        return r.ptr ? reinterpret_cast<T *>((char *)h_->d_scratch + r.off) : nullptr;
+        return r.ptr ? reinterpret_cast<T *>(dev_ + r.off) : nullptr;
     }
     int download()
     {
-        if (total_ > in_end_)
-            VDYN_HIP(h_, hipMemcpyAsync((char *)h_->h_pinned + in_end_, (char *)h_->d_scratch + in_end_,
-                                        total_ - in_end_, hipMemcpyDeviceToHost, h_->stream));
+        if (!mapped_ && total_ > in_end_)
+            VDYN_HIP(h_, hipMemcpyAsync(host_ + in_end_, dev_ + in_end_, total_ - in_end_, hipMemcpyDeviceToHost,
+                                        h_->stream));
         VDYN_HIP(h_, hipStreamSynchronize(h_->stream));
         for (auto &r : outs_)
-            if (r.ptr) std::memcpy(r.ptr, (char *)h_->h_pinned + r.off, r.bytes);
+            if (r.ptr) std::memcpy(r.ptr, host_ + r.off, r.bytes);
         return VDYN_OK;
     }
 
@@ -285,6 +307,8 @@ private:
     VdynHandle *h_;
     std::vector<Region> ins_, outs_;
     size_t in_end_ = 0, total_ = 0;
+    bool mapped_ = false;
+    char *host_ = nullptr, *dev_ = nullptr;
 };
 
 template <typename T>

@@ -182,38 +182,67 @@ class VehicleModel:
     def planar_model(self, state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
         """vehicle_model.py:220-425: returns
         ``[state_dot(10), vx, vy, ax, ay, outputs(18), axc, ayc]`` (:425)."""
-        st, c12, acc = self._pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev)
-        sd, aux, out, ac = (np.empty(k) for k in (10, 4, 18, 2))
-        self._handle(self.device, p).call("vdyn_planar_model_f64_host", 1, _vp(st), _vp(c12), _vp(acc),
-                                          _vp(sd), _vp(aux), _vp(out), _vp(ac))
-        return [sd, aux[0], aux[1], aux[2], aux[3], out, ac[0], ac[1]]
+        h, a = self._pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev)
+        # in: state[0:10] acc_prev[10:12] ctrl12[12:24]; out: state_dot[0:10] aux[10:14] outputs[14:32] acc[32:34]
+        h.call("vdyn_planar_model_f64_host", 1, a[0], a[24], a[20], a[40], a[50], a[54], a[72])
+        o = self._sc_out.copy()                                           # fresh arrays, like the reference
+        return [o[0:10], o[10], o[11], o[12], o[13], o[14:32], o[32], o[33]]
 
     def planar_model_RK4(self, state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
         """vehicle_model.py:427-445: returns
         ``[state_update(10), x, y, yaw, U, state_dot(10), outputs(18), axc, ayc]`` (:445)."""
-        st, c12, acc = self._pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev)
-        s12 = np.concatenate([st, acc])
-        so, sd, out = np.empty(12), np.empty(10), np.empty(18)
-        self._handle(self.device, p).call("vdyn_step_f64_host", 1, _vp(s12), _vp(c12), 12,
-                                          float(self.dt), None, _vp(so), _vp(sd), _vp(out))
-        su = so[:10].copy()
-        return [su, su[8], su[9], su[7], su[0], sd, out, so[10], so[11]]
+        h, a = self._pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev)
+        # out: state12[0:12] state_dot[12:22] outputs[22:40]
+        h.call("vdyn_step_f64_host", 1, a[0], a[24], 12, float(self.dt), None, a[40], a[52], a[62])
+        o = self._sc_out.copy()
+        su = o[0:10]
+        return [su, su[8], su[9], su[7], su[0], o[12:22], o[22:40], o[10], o[11]]
 
-    @staticmethod
-    def _pack_scalar_call(state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
-        st = np.ascontiguousarray(state, dtype=np.float64)         # lists allowed (quirk Q9)
-        tq = np.asarray(tire_torques, dtype=np.float64)
-        mu = np.asarray(mu_max, dtype=np.float64)
-        de = np.asarray(delta, dtype=np.float64)
-        if st.shape != (10,) or tq.shape != (4,) or mu.shape != (4,) or de.shape != (4,):
+    _P_ATTRS = ("m", "a", "b", "Izz", "Jw", "hg", "T", "wL", "wR", "rw", "BFL", "BFR", "BRL", "BRR",
+                "CFL", "CFR", "CRL", "CRR")
+
+    def _scalar_handle(self, p):
+        """Handle for the single-vehicle drop-ins; the VdynParams conversion of `p` is cached
+        and redone only when one of the attributes the path reads has changed."""
+        fp = tuple(getattr(p, a) for a in self._P_ATTRS)
+        if getattr(self, "_scalar_fp", None) != fp:
+            self._scalar_cp = params_to_c(p)
+            self._scalar_key = self._scalar_cp.key()
+            self._scalar_fp = fp
+        h = self._handles.get(self.device)
+        if h is None:
+            h = self._handles[self.device] = _lib.Handle(self._scalar_cp, self.device)
+        h.set_params(self._scalar_cp, self._scalar_key)   # no-op unless another call changed them
+        return h
+
+    def _pack_scalar_call(self, state, tire_torques, mu_max, delta, p, ax_prev, ay_prev):
+        """Single-vehicle calls run 10^4 times per simulated second (drive.py:114): inputs are
+        written into, and outputs read from, two persistent buffers whose addresses are
+        computed once (ndarray.ctypes costs more than the kernel launch)."""
+        if len(state) != 10 or len(tire_torques) != 4 or len(mu_max) != 4 or len(delta) != 4:
             raise ValueError("planar model expects state[10], tire_torques[4], mu_max[4], delta[4]")
+        if getattr(self, "_sc_in", None) is None:
+            self._sc_in, self._sc_out = np.zeros(24), np.zeros(40)
+            bi, bo = self._sc_in.ctypes.data, self._sc_out.ctypes.data
+            # element index -> address: inputs 0..23, outputs 40..79
+            self._sc_addr = {i: C.c_void_p(bi + 8 * i) for i in range(24)}
+            self._sc_addr.update({40 + i: C.c_void_p(bo + 8 * i) for i in range(40)})
+            self._sc_addr[20] = self._sc_addr[10]       # acc_prev sits behind the state
+            self._sc_addr[24] = self._sc_addr[12]       # ctrl12 starts at element 12
+        b = self._sc_in
+        b[0:10] = state                                   # lists allowed (quirk Q9)
+        b[10] = ax_prev
+        b[11] = ay_prev
+        b[12:16] = delta
+        b[16:20] = tire_torques
+        b[20:24] = mu_max
+        h = self._scalar_handle(p)
         # vehicle_model.py:232-235 (quirk Q1): the reference stores mu_max into p.D**
-        for w, v in zip(_WHEELS, mu_max):
-            try:
-                setattr(p, "D" + w, v)
-            except AttributeError:
-                pass
-        return st, np.concatenate([de, tq, mu]), np.array([ax_prev, ay_prev], dtype=np.float64)
+        try:
+            p.DFL, p.DFR, p.DRL, p.DRR = mu_max
+        except AttributeError:
+            pass
+        return h, self._sc_addr
 
     # ----------------------------------------------------------------- batched API
     def step(self, states, controls, dt=None, mu_max=None, p=None, return_diag=False):
