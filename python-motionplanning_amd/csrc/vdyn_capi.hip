@@ -239,7 +239,9 @@ public:
     // Calls this small (the single-vehicle drop-ins of drive.py:141-143) skip both DMA copies:
     // the kernel reads its inputs from, and writes its outputs to, a host-coherent mapped
     // buffer across PCIe, so a call costs one launch and one stream synchronise.
-    static constexpr size_t kMappedBytes = 64 * 1024;
+    // Only for calls of a few KB: every word crosses PCIe on its own, so anything a lane
+    // loops over (waypoint tables, control horizons) must go through HBM instead.
+    static constexpr size_t kMappedBytes = 4 * 1024;
 
     int upload()
     {
