@@ -251,6 +251,17 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     vm.rollout(s2d, c2d)
     t = timed_launches(lambda: vm.rollout(s2d, c2d), 5, torch)
     ex["config2_4096x200_f64"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
+    vmq = type(vm)(2.906, np.deg2rad(30), DT, device=vm.device, lanes_per_rollout=4)
+    vmq.rollout(s2d, c2d)
+    t = timed_launches(lambda: vmq.rollout(s2d, c2d), 5, torch)
+    ex["config2_4096x200_f64_wheel_parallel"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
+    s8 = s0[:, :8192].contiguous()
+    p8 = pid[:8192].contiguous()
+    tab8 = torch.from_numpy(tab).to(dev)
+    for name, m in (("lane", vm), ("wheel_parallel", vmq)):
+        m.rollout(s8, tab8, path_id=p8)
+        t = timed_launches(lambda: m.rollout(s8, tab8, path_id=p8), 5, torch)
+        ex[f"strong_scaling_shard_8192x200_f32_{name}"] = {"steps_per_s": 8192 * HORIZON / t, "kernel_ms": t * 1e3}
     E, C, H = 1024, 512, 50
     ego, cand, goal = (torch.from_numpy(a).to(dev) for a in W.config5(E, C, H))
     vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA)

@@ -14,6 +14,7 @@ from ._build import LIB_PATH
 VDYN_ABI_VERSION = 1
 VDYN_OK, VDYN_ERR_ARG, VDYN_ERR_HIP, VDYN_ERR_NODEV, VDYN_ERR_OOM = 0, -1, -2, -3, -4
 VDYN_CTRL_PER_ROLLOUT, VDYN_CTRL_SHARED = 0, 1
+VDYN_OPT_LANES_PER_ROLLOUT = 1
 
 
 class VdynError(RuntimeError):
@@ -51,6 +52,7 @@ SIGNATURES = {
     "vdyn_destroy": (None, [_vp]),
     "vdyn_last_error": (C.c_char_p, [_vp]),
     "vdyn_stream_synchronize": (_int, [_vp, _vp]),
+    "vdyn_set_option": (_int, [_vp, _int, _int]),
     "vdyn_ctrl_gains_default": (None, [C.POINTER(VdynCtrlGains)]),
 }
 for _s in ("f32", "f64"):

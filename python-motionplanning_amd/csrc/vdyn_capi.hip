@@ -19,6 +19,7 @@ struct VdynHandle {
     size_t d_bytes = 0;
     void *h_pinned = nullptr;
     size_t h_bytes = 0;
+    int lanes_per_rollout = 1;      // VDYN_OPT_LANES_PER_ROLLOUT
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -161,6 +162,16 @@ void vdyn_destroy(VdynHandle *h)
 
 const char *vdyn_last_error(const VdynHandle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int vdyn_set_option(VdynHandle *h, int option, int value)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (option == VDYN_OPT_LANES_PER_ROLLOUT && (value == 0 || value == 1 || value == 4)) {
+        h->lanes_per_rollout = value;
+        return VDYN_OK;
+    }
+    return h->fail(VDYN_ERR_ARG, "vdyn_set_option: unknown option or value");
+}
+
 int vdyn_stream_synchronize(VdynHandle *h, void *stream)
 {
     if (!h) return VDYN_ERR_ARG;
@@ -207,7 +218,10 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
         return h->fail(VDYN_ERR_ARG, w + ": shared controls need path_id and P > 0");
     if (a.traj && a.traj_stride <= 0) return h->fail(VDYN_ERR_ARG, w + ": traj needs traj_stride > 0");
     VDYN_HIP(h, hipSetDevice(h->device));
-    VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, a, (hipStream_t)stream));
+    vdyn::RolloutArgs<T> b = a;
+    // 0 = automatic: wheel-parallel while four lanes per rollout still leave SIMDs to spare
+    b.lanes_per_rollout = h->lanes_per_rollout == 0 ? (a.n <= 16384 ? 4 : 1) : h->lanes_per_rollout;
+    VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, b, (hipStream_t)stream));
     return VDYN_OK;
 }
 

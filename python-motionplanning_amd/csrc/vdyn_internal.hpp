@@ -27,6 +27,7 @@ struct RolloutArgs {
     int traj_stride = 0;
     T *state_dot = nullptr;      // nullable, last step's RK4-averaged derivative [10][n]
     T *outputs = nullptr;        // nullable, last step's RK4-averaged outputs   [18][n]
+    int lanes_per_rollout = 1;   // 1: lane per rollout; 4: wheel-parallel (vdyn_quad.hpp)
 };
 
 template <typename T>

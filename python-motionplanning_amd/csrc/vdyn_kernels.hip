@@ -7,6 +7,7 @@
 #include "vdyn_internal.hpp"
 #include "vdyn_device.hpp"
 #include "vdyn_controls.hpp"
+#include "vdyn_quad.hpp"
 
 namespace vdyn {
 
@@ -116,6 +117,89 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
 #pragma unroll
                 for (int i = 0; i < 18; ++i) outputs_out[(int64_t)i * n + r] = o18.v[i];
             }
+        }
+    }
+}
+
+// Wheel-parallel rollout (vdyn_quad.hpp): four adjacent lanes per rollout, 64 rollouts per
+// 256-thread workgroup.  Same interface as rollout_kernel minus the diagnostics.
+template <typename T, int K, int LAYOUT, bool CS>
+__global__ void __launch_bounds__(kBlock)
+rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
+                    const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
+                    T *__restrict__ terminal, T *__restrict__ traj, int traj_stride)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *tab = reinterpret_cast<T *>(smem_raw);
+
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int q = (int)(gid & 3);
+    const bool active = (gid >> 2) < n;
+    const int64_t r = active ? (gid >> 2) : n - 1;
+    const WheelLane<T> L = make_wheel_lane<T>(P, q);
+
+    QuadState<T> s;
+    s.U = state0[r];
+    s.V = state0[n + r];
+    s.wz = state0[2 * n + r];
+    s.w = state0[(int64_t)(3 + q) * n + r];
+    s.yaw = state0[7 * n + r];
+    s.x = state0[8 * n + r];
+    s.y = state0[9 * n + r];
+    T ax = state0[10 * n + r], ay = state0[11 * n + r];
+    const T mu_k2 = q == 0 ? P.mu[0] : q == 1 ? P.mu[1] : q == 2 ? P.mu[2] : P.mu[3];
+
+    int pid = 0;
+    if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);
+
+    for (int t0 = 0; t0 < H; t0 += chunk) {
+        const int tc_n = min(chunk, H - t0);
+        if (LAYOUT == 1) {
+            __syncthreads();
+            const int total = tc_n * K * Pn;
+            for (int idx = threadIdx.x; idx < total; idx += kBlock) {
+                const int p = idx % Pn;
+                const int kk = (idx / Pn) % K;
+                const int tc = idx / (Pn * K);
+                tab[idx] = ctrl[((int64_t)p * H + (t0 + tc)) * K + kk];
+            }
+            __syncthreads();
+        }
+        for (int tc = 0; tc < tc_n; ++tc) {
+            const int t = t0 + tc;
+            const T *c;
+            int64_t stride;
+            if (LAYOUT == 0) { c = ctrl + ((int64_t)t * K) * n + r; stride = n; }
+            else if (LAYOUT == 1) { c = tab + (int64_t)tc * K * Pn + pid; stride = Pn; }
+            else { c = ctrl + ((int64_t)pid * H + t) * K; stride = 1; }
+            T delta, tq, mu;
+            if (K == 2) {
+                delta = L.front ? c[0] : T(0);          // drive.py:143: [d, d, 0, 0]
+                tq = c[stride];
+                mu = mu_k2;
+            } else {
+                delta = c[(int64_t)q * stride];
+                tq = c[(int64_t)(4 + q) * stride];
+                mu = c[(int64_t)(8 + q) * stride];
+            }
+            rk4_advance_quad<T, CS>(P, L, s, ax, ay, delta, tq, mu, h);
+
+            if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+                row[(int64_t)(3 + q) * n] = s.w;
+                if (q == 0) {
+                    row[0] = s.U; row[n] = s.V; row[2 * n] = s.wz; row[7 * n] = s.yaw;
+                    row[8 * n] = s.x; row[9 * n] = s.y; row[10 * n] = ax; row[11 * n] = ay;
+                }
+            }
+        }
+    }
+    if (active) {
+        terminal[(int64_t)(3 + q) * n + r] = s.w;
+        if (q == 0) {
+            terminal[r] = s.U; terminal[n + r] = s.V; terminal[2 * n + r] = s.wz; terminal[7 * n + r] = s.yaw;
+            terminal[8 * n + r] = s.x; terminal[9 * n + r] = s.y; terminal[10 * n + r] = ax;
+            terminal[11 * n + r] = ay;
         }
     }
 }
@@ -511,6 +595,24 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
     return hipGetLastError();
 }
 
+template <typename T, int K, int LAYOUT, bool CS>
+static hipError_t launch_rollout_quad_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
+{
+    const DevParams<T> P = make_dev_params<T>(p, a.mu4);
+    const unsigned grid = (unsigned)((4 * a.n + kBlock - 1) / kBlock);
+    int chunk = a.H > 0 ? a.H : 1;
+    size_t lds = 0;
+    if (LAYOUT == 1) {
+        const size_t per_step = (size_t)a.P * K * sizeof(T);
+        chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
+        lds = (size_t)chunk * per_step;
+    }
+    hipLaunchKernelGGL((rollout_quad_kernel<T, K, LAYOUT, CS>), dim3(grid), dim3(kBlock), lds, st, P, a.n, a.H,
+                       a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                       a.traj_stride > 0 ? a.traj_stride : 1);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
 {
@@ -519,6 +621,19 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     if (layout == VDYN_CTRL_SHARED && (size_t)a.P * a.k * sizeof(T) > (size_t)kLdsBudget) layout = 2;
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
     const bool cs = shape_factors_small(p);
+    if (a.lanes_per_rollout == 4 && !diag) {
+#define VDYN_DISPATCH_Q(KK, LL)                                                        \
+    if (a.k == KK && layout == LL)                                                     \
+        return cs ? launch_rollout_quad_impl<T, KK, LL, true>(p, a, st)                \
+                  : launch_rollout_quad_impl<T, KK, LL, false>(p, a, st);
+        VDYN_DISPATCH_Q(2, 0)
+        VDYN_DISPATCH_Q(2, 1)
+        VDYN_DISPATCH_Q(2, 2)
+        VDYN_DISPATCH_Q(12, 0)
+        VDYN_DISPATCH_Q(12, 1)
+        VDYN_DISPATCH_Q(12, 2)
+#undef VDYN_DISPATCH_Q
+    }
     // the diagnostic (single-step drop-in) variants are launch-latency bound: general form only
 #define VDYN_DISPATCH(KK, LL)                                                          \
     if (a.k == KK && layout == LL)                                                     \

@@ -148,9 +148,14 @@ class VehicleModel:
 
     ``VehicleModel(wheelbase, max_steer, dt)`` as at drive.py:109; only ``dt``
     matters to this path (vehicle_model.py:93,:428).  ``device`` selects the
-    GPU used for NumPy inputs (torch tensors bring their own device)."""
+    GPU used for NumPy inputs (torch tensors bring their own device).  ``lanes_per_rollout``:
+    1 (default) one lane per rollout; 4 wheel-parallel (for N <= 16384, agrees to rounding);
+    0 automatic (include/vdyn.h, VDYN_OPT_LANES_PER_ROLLOUT)."""
 
-    def __init__(self, wheelbase=1.0, max_steer=0.7, dt=0.05, device=0, params=None):
+    def __init__(self, wheelbase=1.0, max_steer=0.7, dt=0.05, device=0, params=None, lanes_per_rollout=1):
+        if lanes_per_rollout not in (0, 1, 4):
+            raise ValueError("lanes_per_rollout: 1 (lane per rollout), 4 (wheel-parallel) or 0 (automatic)")
+        self.lanes_per_rollout = int(lanes_per_rollout)
         self.dt = dt
         self.wheelbase = wheelbase
         self.max_steer = max_steer
@@ -165,6 +170,7 @@ class VehicleModel:
         h = self._handles.get(device)
         if h is None:
             h = self._handles[device] = _lib.Handle(cp, device)
+            h.call("vdyn_set_option", _lib.VDYN_OPT_LANES_PER_ROLLOUT, self.lanes_per_rollout)
         else:
             h.set_params(cp)
         return h
@@ -212,6 +218,7 @@ class VehicleModel:
         h = self._handles.get(self.device)
         if h is None:
             h = self._handles[self.device] = _lib.Handle(self._scalar_cp, self.device)
+            h.call("vdyn_set_option", _lib.VDYN_OPT_LANES_PER_ROLLOUT, self.lanes_per_rollout)
         h.set_params(self._scalar_cp, self._scalar_key)   # no-op unless another call changed them
         return h
 

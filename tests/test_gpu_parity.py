@@ -562,3 +562,36 @@ def test_safe_path_lanes_beyond_fast_range(gpu_vm, oracle, workloads):
         lanes = big + [77] if dtype == np.float64 else [3, 130, 77]     # fp32 cannot hold yaw = 3e9 + small
         assert parity(got[rows][:, lanes], want[rows][:, lanes], tol * 50, "safe-path lanes") >= 0
         assert np.isfinite(got[:, 101]).all()
+
+
+# ---- wheel-parallel (four lanes per rollout) option ---------------------------------------------
+def test_wheel_parallel_kernel_matches_oracle_and_lane_kernel(pkg, oracle, workloads):
+    """lanes_per_rollout = 4 (vdyn_quad.hpp): same parity bars as the lane-per-rollout kernel on
+    config 2 (fp64), a config-3 slice (fp32, shared LDS controls), k = 12 controls with rear
+    steer, ragged sizes, trajectories; agreement with the default kernel to rounding."""
+    def vm(dt, lanes):
+        return pkg.VehicleModel(2.906, np.deg2rad(30), dt, device=0, lanes_per_rollout=lanes)
+    p = oracle.default_params()
+    s0, ctrl = workloads.config2(64, 200)
+    q = vm(1e-3, 4).rollout(s0, ctrl)
+    want = oracle.rollout(p, s0, ctrl, 1e-3, nthreads=oracle.max_threads())
+    assert parity(q, want, F64_TOL) <= GUARD_F64
+    assert parity(q, vm(1e-3, 1).rollout(s0, ctrl), F64_TOL) <= 1e-12
+    s3, tab, pid = workloads.config3(7001, 200)
+    q32, traj = vm(1e-3, 4).rollout(s3, tab, path_id=pid, traj_stride=40)
+    w3, wt = oracle.rollout(p, s3.astype(np.float64), tab.astype(np.float64), 1e-3, path_id=pid, traj_stride=40,
+                            nthreads=8)
+    assert parity(q32, w3, F32_TOL) <= 2e-4 and parity(traj, wt, F32_TOL) <= 2e-4
+    assert np.array_equal(traj[-1], q32)
+    assert np.array_equal(vm(1e-3, 4).rollout(s3[:, :333], tab, path_id=pid[:333]), q32[:, :333])
+    # k = 12 with rear steer and asymmetric mu (quirks Q1, Q2)
+    g = load_golden("g5_quirks.npz")
+    H, dt = int(g["H"]), float(g["dt"])
+    c = np.concatenate([g["delta"], g["torque"], g["mu"]], axis=1).T
+    term = vm(dt, 4).rollout(g["state0"].T.copy(), np.broadcast_to(c[None], (H, 12, c.shape[1])).copy())
+    assert parity(term, g["terminal"].T, F64_TOL) <= 1e-8
+    # automatic mode picks the wheel-parallel kernel below 16384 rollouts and the lane kernel above
+    auto = vm(1e-3, 0)
+    assert np.array_equal(auto.rollout(s0, ctrl), q)
+    big0, btab, bpid = workloads.config3(20000, 20)
+    assert np.array_equal(auto.rollout(big0, btab, path_id=bpid), vm(1e-3, 1).rollout(big0, btab, path_id=bpid))
