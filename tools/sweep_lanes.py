@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Lane-per-rollout vs wheel-parallel kernel over N (fp32, config-3 workload, H = 200):
+where the automatic mode should switch.  Run on the GPU box: python tools/sweep_lanes.py"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("python-motionplanning_amd")
+W = pkg.workloads
+dev = torch.device("cuda:0")
+
+
+def timed(fn, n=5):
+    fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+for dtype in (np.float32, np.float64):
+    print(dtype.__name__)
+    for N in (2048, 4096, 8192, 16384, 24576, 32768, 40960, 49152, 65536):
+        s0, tab, pid = W.config3(N, 200, dtype)
+        a, b, c = (torch.from_numpy(x).to(dev) for x in (s0, tab, pid))
+        out = []
+        for lanes in (1, 4):
+            vm = pkg.VehicleModel(2.906, 0.52, 1e-3, lanes_per_rollout=lanes)
+            out.append(timed(lambda: vm.rollout(a, b, path_id=c)))
+        print(f"  N={N:6d}  lane {out[0]:.3f} ms   wheel-parallel {out[1]:.3f} ms   ratio {out[0] / out[1]:.2f}")
