@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations")
+    ap.add_argument("--strong", action="store_true",
+                    help="fixed 65536 rollouts split over the ranks (BASELINE configs[3] as worded) instead "
+                         "of the default weak scaling; small shards use the wheel-parallel kernel")
     return ap.parse_args()
 
 
@@ -132,15 +135,17 @@ def main():
 
     pkg = importlib.import_module("python-motionplanning_amd")
     W = pkg.workloads
-    vm = pkg.VehicleModel(2.906, np.deg2rad(30), DT, device=local_rank)
+    n_local = N_PER_GPU // world if args.strong else N_PER_GPU
+    # strong scaling: shards shrink with the rank count -> let the library pick the kernel (0 = auto)
+    vm = pkg.VehicleModel(2.906, np.deg2rad(30), DT, device=local_rank, lanes_per_rollout=0 if args.strong else 1)
 
-    # workload: world * 65536 rollouts, this rank's contiguous 65536-slice, resident in HBM
-    s0_all, tab, pid_all = W.config3(N_PER_GPU * world, HORIZON, np.float32)
-    lo, hi = rank * N_PER_GPU, (rank + 1) * N_PER_GPU
+    # workload: world * n_local rollouts, this rank's contiguous slice, resident in HBM
+    s0_all, tab, pid_all = W.config3(n_local * world, HORIZON, np.float32)
+    lo, hi = rank * n_local, (rank + 1) * n_local
     s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
     pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
-    gathered = torch.empty((world * 12, N_PER_GPU), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * 12, n_local), dtype=torch.float32, device=dev) if world > 1 else None
     del s0_all, pid_all
 
     kern_ev = []
@@ -177,24 +182,25 @@ def main():
     assert bool(torch.isfinite(term).all()), "non-finite terminal states"
 
     kern_s = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) * 1e-3
-    units = world * N_PER_GPU * HORIZON * args.steps
-    steps_per_launch = N_PER_GPU * HORIZON
+    units = world * n_local * HORIZON * args.steps
+    steps_per_launch = n_local * HORIZON
     out = {
         "metric": "RK4 vehicle-steps/sec", "value": units / elapsed, "unit": "vehicle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "rollouts_per_s": world * N_PER_GPU * args.steps / elapsed,
+        "rollouts_per_s": world * n_local * args.steps / elapsed,
         "config": {
             "workload": "BASELINE configs[2]: 65536 rollouts per GPU (ego r//7, lattice path r%7) x 200 "
                         "RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared via LDS; "
                         "N>1: + RCCL all-gather of terminal states [12][65536] per rank",
-            "rollouts_per_gpu": N_PER_GPU, "horizon": HORIZON, "dt": DT, "controls": "shared[7][200][2]",
+            "rollouts_per_gpu": n_local, "horizon": HORIZON, "dt": DT, "controls": "shared[7][200][2]",
         },
     }
     if rank == 0:
         pmc = pmc_summary()
-        algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * N_PER_GPU
+        algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * n_local
         ach = algo_bytes / kern_s / 1e9
         out["roofline"] = {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -221,7 +227,7 @@ def main():
             out["roofline_valu"].update({
                 "valu_insts_per_wave_step": ipw, "issue_rate": issue, "issue_peak": peak_issue,
                 "issue_frac": issue / peak_issue, "issue_frac_of_one_wave_per_simd_ceiling": issue / (peak_issue / 2)})
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and not args.strong:
             out["extra"] = extra_configs(vm, W, torch, dev, s0, tab, pid)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(W)

@@ -1,0 +1,108 @@
+"""CPU: the Python shim's packing / unpacking of the single-vehicle drop-ins and of the batched
+rollout call, exercised end to end against a TEST-ONLY stand-in for the C ABI handle that
+answers with the oracle (the product has no CPU path; this checks the host logic only:
+persistent I/O buffers, pointer offsets, return-list layout, parameter caching)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+
+def _view(ptr, n, dtype=np.float64):
+    addr = ptr.value if isinstance(ptr, C.c_void_p) else ptr
+    return np.ctypeslib.as_array((C.c_double * n).from_address(addr)) if dtype == np.float64 else None
+
+
+class OracleBackedHandle:
+    def __init__(self, oracle):
+        self.O = oracle
+        self.p = oracle.default_params()
+        self.calls = []
+        self.param_sets = 0
+
+    def set_params(self, cp, key=None):
+        self.param_sets += 1
+        for name in ("m", "a", "b", "Izz", "Jw", "hg", "T", "wL", "wR", "rw", "g"):
+            setattr(self.p, name, getattr(cp, name))
+        for i in range(4):
+            self.p.B[i], self.p.C[i] = cp.B[i], cp.C[i]
+
+    def call(self, name, *a):
+        self.calls.append(name)
+        if name == "vdyn_step_f64_host":
+            n, s_in, ctrl, k, dt, mu4, s_out, sd, out = a
+            assert n == 1 and k == 12 and mu4 is None
+            s, c = _view(s_in, 12), _view(ctrl, 12)
+            o = self.O.planar_model_RK4(self.p, dt, s[:10], c[4:8], c[8:12], c[0:4], s[10], s[11])
+            _view(s_out, 12)[:] = np.concatenate([o[0], [o[7], o[8]]])
+            _view(sd, 10)[:] = o[5]
+            _view(out, 18)[:] = o[6]
+        elif name == "vdyn_planar_model_f64_host":
+            n, st, c12, accp, sd, aux, out, acc = a
+            s, c, ap = _view(st, 10), _view(c12, 12), _view(accp, 2)
+            o = self.O.planar_model(self.p, s, c[4:8], c[8:12], c[0:4], ap[0], ap[1])
+            _view(sd, 10)[:] = o[0]
+            _view(aux, 4)[:] = o[1:5]
+            _view(out, 18)[:] = o[5]
+            _view(acc, 2)[:] = o[6:8]
+        elif name == "vdyn_set_option":
+            pass
+        else:
+            raise AssertionError(f"unexpected ABI call {name}")
+
+
+@pytest.fixture
+def vm_mock(pkg, oracle):
+    vm = pkg.VehicleModel(2.906, np.deg2rad(30), 1e-4)
+    h = OracleBackedHandle(oracle)
+    vm._handles[0] = h
+    return vm, h
+
+
+def test_planar_model_RK4_return_list_and_chaining(vm_mock, pkg, oracle):
+    from conftest import load_golden
+    vm, h = vm_mock
+    g = load_golden("g4_closed_loop_world.npz")
+    p = pkg.VehicleParameters()
+    state, ax, ay = list(g["state"][0]), 0, 0                      # a list first (drive.py:64), arrays after
+    for i in range(40):
+        o = vm.planar_model_RK4(state, list(g["torque"][i]), [1.0] * 4, list(g["delta"][i]), p, ax, ay)
+        assert len(o) == 9 and o[0].shape == (10,) and o[5].shape == (10,) and o[6].shape == (18,)
+        assert (o[1], o[2], o[3], o[4]) == (o[0][8], o[0][9], o[0][7], o[0][0])
+        assert np.abs(o[0] - g["state_update"][i]).max() <= 1e-11 * np.abs(g["state_update"][i]).max()
+        assert abs(o[7] - g["acc"][i][0]) <= 1e-10 and abs(o[8] - g["acc"][i][1]) <= 1e-10
+        keep = o[0].copy()
+        state, ax, ay = o[0], o[7], o[8]
+        nxt = vm.planar_model_RK4(state, list(g["torque"][i]), [1.0] * 4, list(g["delta"][i]), p, ax, ay)
+        assert np.array_equal(o[0], keep), "results of an earlier call must not be overwritten by the next"
+        assert nxt[0] is not o[0]
+    assert p.DFL == 1.0 and h.param_sets >= 1
+
+
+def test_planar_model_return_list(vm_mock, pkg):
+    from conftest import load_golden
+    vm, _ = vm_mock
+    g = load_golden("g2_deriv.npz")
+    for i in (0, 9, 33):
+        o = vm.planar_model(g["state"][i], g["torque"][i], g["mu"][i], g["delta"][i], pkg.VehicleParameters(),
+                            *g["ax_ay_prev"][i])
+        assert len(o) == 8 and o[0].shape == (10,) and o[5].shape == (18,)
+        assert np.abs(o[0] - g["state_dot"][i]).max() <= 1e-11 * np.abs(g["state_dot"][i]).max()
+        assert np.abs(np.array(o[1:5]) - g["aux"][i]).max() <= 1e-11 * np.abs(g["aux"][i]).max()
+        assert np.abs(np.array(o[6:8]) - g["acc"][i]).max() <= 1e-11 * np.abs(g["acc"][i]).max()
+
+
+def test_parameter_changes_are_noticed(vm_mock, pkg):
+    vm, h = vm_mock
+    p = pkg.VehicleParameters()
+    st = [25.0, 0, 0] + [25.0 / p.rw] * 4 + [0, 0, 0]
+    a = vm.planar_model_RK4(st, [100.0] * 4, [1.0] * 4, [0.05, 0.05, 0, 0], p, 0, 0)[0]
+    n0 = h.param_sets
+    vm.planar_model_RK4(st, [100.0] * 4, [1.0] * 4, [0.05, 0.05, 0, 0], p, 0, 0)
+    p.BFL = p.BFR = 12.0                                           # softer front tires (vehicle_model.py:237-242)
+    b = vm.planar_model_RK4(st, [100.0] * 4, [1.0] * 4, [0.05, 0.05, 0, 0], p, 0, 0)[0]
+    assert h.param_sets > n0 and not np.array_equal(a, b)
+    q = pkg.VehicleParameters(mf=1200.0)                           # a different object altogether
+    c = vm.planar_model_RK4(st, [100.0] * 4, [1.0] * 4, [0.05, 0.05, 0, 0], q, 0, 0)[0]
+    assert not np.array_equal(b, c)
