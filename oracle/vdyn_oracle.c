@@ -26,6 +26,8 @@ int oracle_max_threads(void)
 #define FABS fabs
 #define ATAN2 atan2
 #define FMOD fmod
+#define POW pow
+#define FLOOR floor
 #include "vdyn_oracle_body.inc"
 #undef REAL
 #undef X
@@ -36,6 +38,8 @@ int oracle_max_threads(void)
 #undef FABS
 #undef ATAN2
 #undef FMOD
+#undef POW
+#undef FLOOR
 
 #define REAL float
 #define X(name) name##_f32
@@ -46,4 +50,6 @@ int oracle_max_threads(void)
 #define FABS fabsf
 #define ATAN2 atan2f
 #define FMOD fmodf
+#define POW powf
+#define FLOOR floorf
 #include "vdyn_oracle_body.inc"

@@ -63,6 +63,17 @@ typedef struct OracleCtrlParams {
                                     const double *offsets, const double *radii, int nc,                \
                                     const REAL *goal, double weight, int *collision_free,              \
                                     int *best_idx, REAL *best_score, int nthreads);                    \
+    int oracle_closest_index_##S(const REAL *px, const REAL *py, int n, REAL ex, REAL ey, REAL *len);   \
+    int oracle_goal_index_##S(const REAL *px, const REAL *py, int n, REAL lookahead, REAL closest_len,  \
+                              int closest_index);                                                       \
+    void oracle_goal_state_set_##S(const REAL *px, const REAL *py, int n, int goal_index, REAL goal_v,  \
+                                   const REAL *ego, int P, REAL path_offset, REAL *out);                \
+    REAL oracle_spiral_objective_##S(const REAL *p, REAL xf, REAL yf, REAL tf, REAL *grad);             \
+    void oracle_sample_spiral_##S(const REAL *p, REAL *x, REAL *y, REAL *t);                            \
+    void oracle_transform_path_##S(const REAL *x, const REAL *y, const REAL *t, int L, const REAL *ego, \
+                                   REAL *gx, REAL *gy, REAL *gt);                                       \
+    int oracle_interpolate_waypoints_##S(const REAL *x, const REAL *y, int L, REAL v, REAL res,         \
+                                         REAL *out, int max_rows);                                      \
     int oracle_mpc_argmin_##S(const OracleParams *p, int E, int C, int H, double dt,           \
                               const REAL *ego, const REAL *cand, const REAL *goal,             \
                               REAL w_delta, REAL *best_cost, int *best_idx, REAL *cost_all,    \

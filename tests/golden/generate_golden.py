@@ -412,7 +412,105 @@ def g10():
           np.bincount(fr.sum(axis=1), minlength=8), "best", np.bincount(np.array(best_l) + 1, minlength=8))
 
 
+_G11 = {"closest": [], "goal_index": [], "goal_set": [], "opt": [], "plan": [], "transform": []}
+
+
+def g11():
+    """Lattice generation (local_planner.py:25-52,85-347,424-470; path_optimizer.py:31-175):
+    every intermediate of the 3 planning cycles of the G4/G9 run -- closest / goal index, the 7
+    goal states, L-BFGS-B's optimum per goal, the sampled spirals, validity, the transformed
+    paths -- plus 48 seeded goal states optimised and sampled through PathOptimizer directly."""
+    import scipy.integrate
+    import scipy.optimize
+    if not hasattr(scipy.integrate, "cumtrapz"):
+        scipy.integrate.cumtrapz = scipy.integrate.cumulative_trapezoid
+    import libs.vehicle_model.drive as drive
+    import libs.motionplanner.local_planner as lp
+    from libs.motionplanner.path_optimizer import PathOptimizer
+    from libs.utils.env import world
+    drive.os.system = lambda *_a, **_k: 0
+    rec = _G11
+    orig = dict(closest=lp.get_closest_index, gi=lp.LocalPlanner.get_goal_index,
+                gs=lp.LocalPlanner.get_goal_state_set, pp=lp.LocalPlanner.plan_paths, tr=lp.transform_paths,
+                mini=scipy.optimize.minimize)
+
+    def closest(waypoints, ego_state):
+        o = orig["closest"](waypoints, ego_state)
+        rec["closest"].append((np.array(ego_state, float), float(o[0]), int(o[1])))
+        return o
+
+    def goal_index(self, waypoints, ego_state, closest_len, closest_index):
+        o = orig["gi"](self, waypoints, ego_state, closest_len, closest_index)
+        rec["goal_index"].append(int(o))
+        return o
+
+    def goal_set(self, goal_index, goal_state, waypoints, ego_state):
+        o = orig["gs"](self, goal_index, goal_state, waypoints, ego_state)
+        rec["goal_set"].append(np.array(o, float))
+        return o
+
+    def minimize(fun, x0, **kw):
+        r = orig["mini"](fun, x0, **kw)
+        rec["opt"].append((np.array(x0, float), np.array(r.x, float), float(r.fun), int(r.nit)))
+        return r
+
+    def plan_paths(self, goal_state_set):
+        paths, validity = orig["pp"](self, goal_state_set)
+        rec["plan"].append(([[np.array(r, float) for r in pth] for pth in paths], np.array(validity, bool)))
+        return paths, validity
+
+    def transform(paths, ego_state):
+        o = orig["tr"](paths, ego_state)
+        rec["transform"].append(np.array(o, float))
+        return o
+
+    lp.get_closest_index, lp.LocalPlanner.get_goal_index = closest, goal_index
+    lp.LocalPlanner.get_goal_state_set, lp.LocalPlanner.plan_paths, lp.transform_paths = goal_set, plan_paths, transform
+    scipy.optimize.minimize = minimize
+    path = world.path
+    car = drive.Car(path.px[10], path.py[10], path.pyaw[10], path.px, path.py, path.pyaw,
+                    0.01 / drive.Veh_SIM_NUM)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for fr in range(3):
+            car.drive(fr)
+    n_plan = len(rec["plan"])
+    # direct optimiser calls on seeded goals (the range the planner produces: 30 m ahead, +-6 m)
+    rng = np.random.default_rng(11)
+    goals = np.stack([rng.uniform(12, 40, 48), rng.uniform(-7, 7, 48), rng.uniform(-0.4, 0.4, 48)], axis=1)
+    po = PathOptimizer()
+    direct = []
+    for xf, yf, tf in goals:
+        k = len(rec["opt"])
+        sp = po.optimize_spiral(xf, yf, tf)
+        direct.append((rec["opt"][k][1], np.array(sp[0]), np.array(sp[1]), np.array(sp[2])))
+    scipy.optimize.minimize = orig["mini"]
+    lp.get_closest_index, lp.LocalPlanner.get_goal_index = orig["closest"], orig["gi"]
+    lp.LocalPlanner.get_goal_state_set, lp.LocalPlanner.plan_paths, lp.transform_paths = orig["gs"], orig["pp"], orig["tr"]
+    assert n_plan == 3 and all(v.all() for _, v in rec["plan"])
+    np.savez_compressed(
+        os.path.join(HERE, "g11_lattice.npz"),
+        px=np.array(path.px, float), py=np.array(path.py, float), target_vel=np.float64(car.target_vel),
+        ego=np.array([c[0] for c in rec["closest"]]), closest_len=np.array([c[1] for c in rec["closest"]]),
+        closest_index=np.array([c[2] for c in rec["closest"]]), goal_index=np.array(rec["goal_index"]),
+        goal_set=np.array(rec["goal_set"]),                                             # [3][7][4]
+        opt_x0=np.array([o[0] for o in rec["opt"][:21]]).reshape(3, 7, 3),
+        opt_x=np.array([o[1] for o in rec["opt"][:21]]).reshape(3, 7, 3),
+        opt_fun=np.array([o[2] for o in rec["opt"][:21]]).reshape(3, 7),
+        spiral_x=np.array([[p[0] for p in pl[0]] for pl in rec["plan"]]),               # [3][7][49]
+        spiral_y=np.array([[p[1] for p in pl[0]] for pl in rec["plan"]]),
+        spiral_t=np.array([[p[2] for p in pl[0]] for pl in rec["plan"]]),               # [3][7][50]
+        validity=np.array([pl[1] for pl in rec["plan"]]), transformed=np.array(rec["transform"]),  # [3][7][3][49]
+        direct_goals=goals, direct_x=np.array([d[0] for d in direct]),
+        direct_sx=np.array([d[1] for d in direct]), direct_sy=np.array([d[2] for d in direct]),
+        direct_st=np.array([d[3] for d in direct]),
+        consts=np.array([drive.LOOKAHEAD, drive.NUM_PATHS, drive.PATH_OFFSET, lp.INTERP_DISTANCE_RES], float))
+    print("G11 closest", [c[2] for c in rec["closest"]], "goal", rec["goal_index"], "nit",
+          [o[3] for o in rec["opt"][:21]])
+    print("   opt_x[0]:", rec["opt"][0][1], "direct max nit", max(o[3] for o in rec["opt"][21:]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -235,3 +235,60 @@ def test_g10_collision_and_selection(oracle):
     f2, b2, s2 = oracle.select_best_path(g["paths"][:3], g["obstacles"][0], g["goal"][:3].T.copy())
     assert np.array_equal(f2, g["collision_free"][:3]) and np.array_equal(b2, g["best_index"][:3])
     assert E == 63
+
+
+# ---- "next" row 3: lattice generation (G11) --------------------------------------------------------
+def test_g11_planning_cycles(oracle):
+    """3 planning cycles of the reference's Car.drive: indices exact; goal states, sampled
+    spirals and transformed paths at rounding level when fed the reference's own optimum;
+    the restated objective reproduces L-BFGS-B's optimum through the same SciPy call."""
+    g = load_golden("g11_lattice.npz")
+    look, P, off, res = g["consts"]
+    for f in range(3):
+        o = oracle.plan_paths(g["px"], g["py"], g["ego"][f], float(g["target_vel"]), look, int(P), off,
+                              spiral_params=g["opt_x"][f])
+        assert o["closest_index"] == g["closest_index"][f] and o["goal_index"] == g["goal_index"][f]
+        assert abs(o["closest_len"] - g["closest_len"][f]) <= 1e-14
+        close(o["goal_set"], g["goal_set"][f], 1e-12)
+        close(o["spiral_x"], g["spiral_x"][f], 1e-12)
+        close(o["spiral_y"], g["spiral_y"][f], 1e-12)
+        close(o["spiral_t"], g["spiral_t"][f], 1e-12)
+        assert np.array_equal(o["validity"], g["validity"][f])
+        close(o["paths"], g["transformed"][f], 1e-12)
+        full = oracle.plan_paths(g["px"], g["py"], g["ego"][f], float(g["target_vel"]), look, int(P), off)
+        close(full["params"], g["opt_x"][f], 1e-6)
+        close(full["paths"], g["transformed"][f], 1e-6)
+
+
+def test_g11_objective_optimum_and_samples(oracle):
+    g = load_golden("g11_lattice.npz")
+    for i in range(len(g["direct_goals"])):
+        xf, yf, tf = g["direct_goals"][i]
+        J, grad = oracle.spiral_objective(g["direct_x"][i], xf, yf, tf)
+        # finite-difference check of the restated gradient
+        for k in range(3):
+            h = 1e-6 * max(1.0, abs(g["direct_x"][i][k]))
+            pp, pm = g["direct_x"][i].copy(), g["direct_x"][i].copy()
+            pp[k] += h
+            pm[k] -= h
+            fd = (oracle.spiral_objective(pp, xf, yf, tf)[0] - oracle.spiral_objective(pm, xf, yf, tf)[0]) / (2 * h)
+            assert abs(fd - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))
+        close(oracle.optimize_spiral(xf, yf, tf), g["direct_x"][i], 1e-6)
+        x, y, t = oracle.sample_spiral(g["direct_x"][i])
+        close(x, g["direct_sx"][i], 1e-12)
+        close(y, g["direct_sy"][i], 1e-12)
+        close(t, g["direct_st"][i], 1e-12)
+
+
+def test_g11_waypoint_interpolation(oracle):
+    """The 1 cm re-interpolation the planner hands to the Stanley controller (G9's tables) from
+    the best path of each cycle (the index select_best_path_index returned, G10)."""
+    g = load_golden("g11_lattice.npz")
+    g9 = load_golden("g9_closed_loop_controls.npz")
+    g10 = load_golden("g10_collision_select.npz")
+    for f in range(3):
+        best = g["transformed"][f][g10["best_index"][f]]
+        wp = oracle.interpolate_waypoints(best[0], best[1], float(g["target_vel"]), float(g["consts"][3]))
+        want = g9["waypoints"][f, :g9["waypoint_count"][f]]
+        assert wp.shape == want.shape
+        close(wp, want, 1e-12)
