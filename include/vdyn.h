@@ -286,6 +286,60 @@ int vdyn_select_best_path_f32_host(VdynHandle *h, int32_t E, int32_t P, int32_t 
                                    const float *goal, double weight, const int32_t *collision_in,
                                    int32_t *collision_free, int32_t *best_idx, float *best_score);
 
+/* ==== "next" row: lattice generation ========================================================
+ * Replaces, for E egos at once, the planning cycle of LocalPlanner.MotionPlanner up to the
+ * transformed lattice (local_planner.py:362-368):
+ *   get_closest_index (:25-52), get_goal_index (:85-152), get_goal_state_set (:154-275),
+ *   plan_paths (:277-323) = PathOptimizer.optimize_spiral (path_optimizer.py:31-88) +
+ *   sample_spiral (:131-175) + the validity test (:317-321), transform_paths (:424-470).
+ * px, py [nwp]: the global path (drive.py:117: self.px, self.py); ego [3][E] rows x, y, yaw;
+ * goal_v = target_vel; lookahead, P (= num_paths), path_offset: drive.py:21,24,35.
+ * params_in (nullable) [E][P][3] = (p1, p2, sf) per spiral: skips the optimiser.
+ * The optimiser is NOT SciPy's L-BFGS-B (path_optimizer.py:84): the same objective
+ * (path_optimizer.py:183-198) over the same bounds (:78) is minimised by a projected
+ * Levenberg-Marquardt iteration; results agree with the reference to the optimiser's tolerance.
+ * -> closest_idx [E], goal_idx [E], closest_len (nullable) [E], goal_set [E][P][4] (x, y, t, v in
+ *    the vehicle frame), params [E][P][3], paths [E][P][3][49] (rows x, y, yaw, global frame:
+ *    the reference's path lists), validity [E][P] (1 = kept, :317-321), cost [E][P] (objective). */
+int vdyn_plan_lattice_f64_dev(VdynHandle *h, int32_t E, const double *px, const double *py, int32_t nwp,
+                              const double *ego, double goal_v, double lookahead, int32_t P, double path_offset,
+                              const double *params_in, int32_t *closest_idx, int32_t *goal_idx,
+                              double *closest_len, double *goal_set, double *params, double *paths,
+                              int32_t *validity, double *cost, void *stream);
+int vdyn_plan_lattice_f32_dev(VdynHandle *h, int32_t E, const float *px, const float *py, int32_t nwp,
+                              const float *ego, double goal_v, double lookahead, int32_t P, double path_offset,
+                              const float *params_in, int32_t *closest_idx, int32_t *goal_idx,
+                              float *closest_len, float *goal_set, float *params, float *paths,
+                              int32_t *validity, float *cost, void *stream);
+int vdyn_plan_lattice_f64_host(VdynHandle *h, int32_t E, const double *px, const double *py, int32_t nwp,
+                               const double *ego, double goal_v, double lookahead, int32_t P, double path_offset,
+                               const double *params_in, int32_t *closest_idx, int32_t *goal_idx,
+                               double *closest_len, double *goal_set, double *params, double *paths,
+                               int32_t *validity, double *cost);
+int vdyn_plan_lattice_f32_host(VdynHandle *h, int32_t E, const float *px, const float *py, int32_t nwp,
+                               const float *ego, double goal_v, double lookahead, int32_t P, double path_offset,
+                               const float *params_in, int32_t *closest_idx, int32_t *goal_idx,
+                               float *closest_len, float *goal_set, float *params, float *paths,
+                               int32_t *validity, float *cost);
+
+/* Replaces: the waypoint re-interpolation of local_planner.py:395-419 (INTERP_DISTANCE_RES =
+ * 0.01, :19) that feeds StanleyController.update_waypoints: for every ego, path best_idx[e] of
+ * paths [E][P][3][L] is resampled to `res` spacing.
+ * -> wp_out [E][Wmax][2] (x, y), wcount [E] (0 when best_idx[e] < 0 or Wmax is too small): the
+ *    waypoint tables vdyn_closed_loop_* / vdyn_controller_update_* take.                       */
+int vdyn_interpolate_waypoints_f64_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *paths,
+                                       const int32_t *best_idx, double res, int32_t Wmax, double *wp_out,
+                                       int32_t *wcount, void *stream);
+int vdyn_interpolate_waypoints_f32_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const float *paths,
+                                       const int32_t *best_idx, double res, int32_t Wmax, float *wp_out,
+                                       int32_t *wcount, void *stream);
+int vdyn_interpolate_waypoints_f64_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *paths,
+                                        const int32_t *best_idx, double res, int32_t Wmax, double *wp_out,
+                                        int32_t *wcount);
+int vdyn_interpolate_waypoints_f32_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const float *paths,
+                                        const int32_t *best_idx, double res, int32_t Wmax, float *wp_out,
+                                        int32_t *wcount);
+
 #ifdef __cplusplus
 }
 #endif

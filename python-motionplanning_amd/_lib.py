@@ -85,6 +85,14 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_select_best_path_{_s}_host"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp,
                                                              _vp, _i32, _vp, _dbl, _vp, _vp, _vp, _vp])
 
+for _s in ("f32", "f64"):
+    _pl = [_vp, _i32, _vp, _vp, _i32, _vp, _dbl, _dbl, _i32, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    SIGNATURES[f"vdyn_plan_lattice_{_s}_dev"] = (_int, _pl + [_vp])
+    SIGNATURES[f"vdyn_plan_lattice_{_s}_host"] = (_int, _pl)
+    _iw = [_vp, _i32, _i32, _i32, _vp, _vp, _dbl, _i32, _vp, _vp]
+    SIGNATURES[f"vdyn_interpolate_waypoints_{_s}_dev"] = (_int, _iw + [_vp])
+    SIGNATURES[f"vdyn_interpolate_waypoints_{_s}_host"] = (_int, _iw)
+
 _lib = None
 
 

@@ -540,6 +540,101 @@ int select_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, 
 }
 
 template <typename T>
+int lattice_dev(VdynHandle *h, const vdyn::LatticeArgs<T> &a, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (a.E < 0 || a.P <= 0 || a.nwp < 2) return h->fail(VDYN_ERR_ARG, "plan_lattice: need E >= 0, P > 0, nwp >= 2");
+    if (!std::isfinite(a.goal_v) || !std::isfinite(a.lookahead) || !std::isfinite(a.path_offset))
+        return h->fail(VDYN_ERR_ARG, "plan_lattice: non-finite scalar");
+    if (a.E == 0) return VDYN_OK;
+    if (!a.px || !a.py || !a.ego || !a.closest_idx || !a.goal_idx || !a.goal_set || !a.params || !a.paths ||
+        !a.validity || !a.cost)
+        return h->fail(VDYN_ERR_ARG, "plan_lattice: null buffer");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_plan_lattice<T>(a, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int lattice_host(VdynHandle *h, vdyn::LatticeArgs<T> a)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (a.E <= 0 || a.P <= 0 || a.nwp < 2 || !a.px || !a.py || !a.ego)
+        return a.E == 0 ? VDYN_OK : lattice_dev<T>(h, a, h->stream);
+    const size_t EP = (size_t)a.E * a.P;
+    Stage s(h);
+    const size_t i0 = s.in(a.px, sizeof(T) * (size_t)a.nwp), i1 = s.in(a.py, sizeof(T) * (size_t)a.nwp),
+                 i2 = s.in(a.ego, sizeof(T) * 3 * (size_t)a.E), i3 = s.in(a.params_in, sizeof(T) * 3 * EP);
+    // closest_len is needed on the device even when the caller does not want it back
+    T dummy = 0;
+    const bool want_len = a.closest_len != nullptr;
+    const size_t o0 = s.out(a.closest_idx, sizeof(int32_t) * (size_t)a.E),
+                 o1 = s.out(a.goal_idx, sizeof(int32_t) * (size_t)a.E),
+                 o2 = s.out(want_len ? a.closest_len : &dummy, sizeof(T) * (want_len ? (size_t)a.E : 1)),
+                 o3 = s.out(a.goal_set, sizeof(T) * 4 * EP), o4 = s.out(a.params, sizeof(T) * 3 * EP),
+                 o5 = s.out(a.paths, sizeof(T) * 3 * 49 * EP), o6 = s.out(a.validity, sizeof(int32_t) * EP),
+                 o7 = s.out(a.cost, sizeof(T) * EP);
+    int rc = s.upload();
+    if (rc) return rc;
+    a.px = s.dev<T>(i0, false); a.py = s.dev<T>(i1, false); a.ego = s.dev<T>(i2, false);
+    a.params_in = s.dev<T>(i3, false);
+    a.closest_idx = s.dev<int>(o0, true); a.goal_idx = s.dev<int>(o1, true);
+    a.closest_len = want_len ? s.dev<T>(o2, true) : nullptr;
+    a.goal_set = s.dev<T>(o3, true); a.params = s.dev<T>(o4, true); a.paths = s.dev<T>(o5, true);
+    a.validity = s.dev<int>(o6, true); a.cost = s.dev<T>(o7, true);
+    rc = lattice_dev<T>(h, a, h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+vdyn::LatticeArgs<T> lattice_args(int32_t E, const T *px, const T *py, int32_t nwp, const T *ego, double goal_v,
+                                  double lookahead, int32_t P, double path_offset, const T *params_in,
+                                  int32_t *closest_idx, int32_t *goal_idx, T *closest_len, T *goal_set, T *params,
+                                  T *paths, int32_t *validity, T *cost)
+{
+    vdyn::LatticeArgs<T> a;
+    a.E = E; a.P = P; a.nwp = nwp; a.px = px; a.py = py; a.ego = ego; a.goal_v = goal_v; a.lookahead = lookahead;
+    a.path_offset = path_offset; a.params_in = params_in; a.closest_idx = closest_idx; a.goal_idx = goal_idx;
+    a.closest_len = closest_len; a.goal_set = goal_set; a.params = params; a.paths = paths; a.validity = validity;
+    a.cost = cost;
+    return a;
+}
+
+template <typename T>
+int interp_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, const int32_t *best_idx, double res,
+               int32_t Wmax, T *wp_out, int32_t *wcount, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (E < 0 || P <= 0 || L < 2 || Wmax < 2 || !(res > 0))
+        return h->fail(VDYN_ERR_ARG, "interpolate_waypoints: need E >= 0, P > 0, L >= 2, Wmax >= 2, res > 0");
+    if (E == 0) return VDYN_OK;
+    if (!paths || !best_idx || !wp_out || !wcount) return h->fail(VDYN_ERR_ARG, "interpolate_waypoints: null buffer");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_interpolate_waypoints<T>(E, P, L, paths, best_idx, res, Wmax, wp_out, wcount,
+                                                      (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int interp_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, const int32_t *best_idx, double res,
+                int32_t Wmax, T *wp_out, int32_t *wcount)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (E <= 0 || P <= 0 || L < 2 || Wmax < 2 || !paths || !best_idx || !wp_out || !wcount)
+        return E == 0 ? VDYN_OK : interp_dev<T>(h, E, P, L, paths, best_idx, res, Wmax, wp_out, wcount, h->stream);
+    Stage s(h);
+    const size_t i0 = s.in(paths, sizeof(T) * (size_t)E * P * 3 * L), i1 = s.in(best_idx, sizeof(int32_t) * (size_t)E);
+    const size_t o0 = s.out(wp_out, sizeof(T) * (size_t)E * Wmax * 2), o1 = s.out(wcount, sizeof(int32_t) * (size_t)E);
+    int rc = s.upload();
+    if (rc) return rc;
+    rc = interp_dev<T>(h, E, P, L, s.dev<T>(i0, false), s.dev<int>(i1, false), res, Wmax, s.dev<T>(o0, true),
+                       s.dev<int>(o1, true), h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
 vdyn::RolloutArgs<T> step_args(int64_t n, const T *state_in, const T *ctrl, int k, double dt,
                                const double *mu4, T *state_out, T *state_dot, T *outputs)
 {
@@ -685,8 +780,45 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
                               goal, weight, collision_in, collision_free, best_idx, best_score);                       \
     }
 
+#define VDYN_DEFINE_LATTICE_ABI(S, T)                                                                    \
+    extern "C" int vdyn_plan_lattice_##S##_dev(                                                          \
+        VdynHandle *h, int32_t E, const T *px, const T *py, int32_t nwp, const T *ego, double goal_v,    \
+        double lookahead, int32_t P, double path_offset, const T *params_in, int32_t *closest_idx,       \
+        int32_t *goal_idx, T *closest_len, T *goal_set, T *params, T *paths, int32_t *validity, T *cost, \
+        void *stream)                                                                                    \
+    {                                                                                                    \
+        return lattice_dev<T>(h, lattice_args<T>(E, px, py, nwp, ego, goal_v, lookahead, P, path_offset, \
+                                                 params_in, closest_idx, goal_idx, closest_len, goal_set, \
+                                                 params, paths, validity, cost), stream);                \
+    }                                                                                                    \
+    extern "C" int vdyn_plan_lattice_##S##_host(                                                         \
+        VdynHandle *h, int32_t E, const T *px, const T *py, int32_t nwp, const T *ego, double goal_v,    \
+        double lookahead, int32_t P, double path_offset, const T *params_in, int32_t *closest_idx,       \
+        int32_t *goal_idx, T *closest_len, T *goal_set, T *params, T *paths, int32_t *validity, T *cost) \
+    {                                                                                                    \
+        return lattice_host<T>(h, lattice_args<T>(E, px, py, nwp, ego, goal_v, lookahead, P, path_offset, \
+                                                  params_in, closest_idx, goal_idx, closest_len, goal_set, \
+                                                  params, paths, validity, cost));                       \
+    }                                                                                                    \
+    extern "C" int vdyn_interpolate_waypoints_##S##_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L,  \
+                                                        const T *paths, const int32_t *best_idx,         \
+                                                        double res, int32_t Wmax, T *wp_out,             \
+                                                        int32_t *wcount, void *stream)                   \
+    {                                                                                                    \
+        return interp_dev<T>(h, E, P, L, paths, best_idx, res, Wmax, wp_out, wcount, stream);            \
+    }                                                                                                    \
+    extern "C" int vdyn_interpolate_waypoints_##S##_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, \
+                                                         const T *paths, const int32_t *best_idx,        \
+                                                         double res, int32_t Wmax, T *wp_out,            \
+                                                         int32_t *wcount)                                \
+    {                                                                                                    \
+        return interp_host<T>(h, E, P, L, paths, best_idx, res, Wmax, wp_out, wcount);                   \
+    }
+
 VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
+VDYN_DEFINE_LATTICE_ABI(f32, float)
+VDYN_DEFINE_LATTICE_ABI(f64, double)
 VDYN_DEFINE_SELECT_ABI(f32, float)
 VDYN_DEFINE_SELECT_ABI(f64, double)
 VDYN_DEFINE_CTRL_ABI(f32, float)

@@ -89,4 +89,26 @@ struct SelectArgs {
 template <typename T>
 hipError_t launch_select_best_path(const SelectArgs<T> &a, hipStream_t st);
 
+template <typename T>
+struct LatticeArgs {
+    int E = 0, P = 0, nwp = 0;
+    const T *px = nullptr, *py = nullptr;   // global path [nwp]
+    const T *ego = nullptr;                 // [3][E]: x, y, yaw
+    double goal_v = 0, lookahead = 0, path_offset = 0;
+    const T *params_in = nullptr;           // nullable [E][P][3]: skip the optimiser
+    int *closest_idx = nullptr, *goal_idx = nullptr;   // [E]
+    T *closest_len = nullptr;               // [E]
+    T *goal_set = nullptr;                  // [E][P][4]
+    T *params = nullptr;                    // [E][P][3]
+    T *paths = nullptr;                     // [E][P][3][49]
+    int *validity = nullptr;                // [E][P]
+    T *cost = nullptr;                      // [E][P]
+};
+
+template <typename T>
+hipError_t launch_plan_lattice(const LatticeArgs<T> &a, hipStream_t st);
+template <typename T>
+hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, const int *best_idx, double res,
+                                        int Wmax, T *wp_out, int *wcount, hipStream_t st);
+
 }  // namespace vdyn

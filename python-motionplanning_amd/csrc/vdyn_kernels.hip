@@ -8,6 +8,7 @@
 #include "vdyn_device.hpp"
 #include "vdyn_controls.hpp"
 #include "vdyn_quad.hpp"
+#include "vdyn_lattice.hpp"
 
 namespace vdyn {
 
@@ -541,6 +542,115 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
     }
 }
 
+// Lattice generation, stage 1: one lane per ego -- closest and goal index on the global path
+// (local_planner.py:25-52, :85-152).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+lattice_index_kernel(int E, const T *__restrict__ px, const T *__restrict__ py, int nwp, const T *__restrict__ ego,
+                     T lookahead, int *__restrict__ closest_idx, int *__restrict__ goal_idx,
+                     T *__restrict__ closest_len)
+{
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E) return;
+    int ci;
+    T len;
+    closest_index<T>(px, py, nwp, ego[e], ego[(int64_t)E + e], ci, len);
+    closest_idx[e] = ci;
+    if (closest_len != nullptr) closest_len[e] = len;
+    goal_idx[e] = goal_index<T>(px, py, nwp, lookahead, len, ci);
+}
+
+// Stage 2: one lane per (ego, lateral offset) -- goal state (:154-275), spiral optimisation
+// (path_optimizer.py:31-88; skipped when params_in is given), sampling, validity, transform.
+//   goal_set [E][P][4], params [E][P][3], paths [E][P][3][49], validity [E][P], cost [E][P]
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+lattice_paths_kernel(int E, int P, const T *__restrict__ px, const T *__restrict__ py, int nwp,
+                     const T *__restrict__ ego, const int *__restrict__ goal_idx, T goal_v, T path_offset,
+                     const T *__restrict__ params_in, T *__restrict__ goal_set, T *__restrict__ params,
+                     T *__restrict__ paths, int *__restrict__ validity, T *__restrict__ cost)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gid < (int64_t)E * P;
+    const int64_t id = active ? gid : (int64_t)E * P - 1;
+    const int e = (int)(id / P), k = (int)(id - (int64_t)e * P);
+    const T ex = ego[e], ey = ego[(int64_t)E + e], eyaw = ego[2 * (int64_t)E + e];
+    T gx, gy, gt;
+    goal_state<T>(px, py, nwp, goal_idx[e], ex, ey, eyaw, k, P, path_offset, gx, gy, gt);
+    T p[3], J;
+    int iters = 0;
+    if (params_in != nullptr) {
+        T r[5], Jc[5][3];
+        p[0] = params_in[3 * id]; p[1] = params_in[3 * id + 1]; p[2] = params_in[3 * id + 2];
+        J = spiral_residuals<T>(p[0], p[1], p[2], gx, gy, gt, r, Jc);
+    } else {
+        J = optimize_spiral<T>(gx, gy, gt, p, iters);     // every lane of the wave iterates together
+    }
+    if (!active) return;
+    T *out = paths + id * 3 * kSpiralPoints;
+    const bool ok = sample_and_transform<T>(p, gx, gy, gt, ex, ey, eyaw, out, out + kSpiralPoints,
+                                            out + 2 * kSpiralPoints, 1);
+    goal_set[4 * id] = gx; goal_set[4 * id + 1] = gy; goal_set[4 * id + 2] = gt; goal_set[4 * id + 3] = goal_v;
+    params[3 * id] = p[0]; params[3 * id + 1] = p[1]; params[3 * id + 2] = p[2];
+    validity[id] = ok ? 1 : 0;
+    cost[id] = J;
+}
+
+// Waypoint re-interpolation (local_planner.py:395-419) of path best_idx[e] of every ego to `res`
+// spacing: one workgroup per ego; each lane owns one segment of the 48.
+//   wp_out [E][Wmax][2] (x, y), wcount [E]; an ego with best_idx < 0 or too many points gets 0.
+template <typename T>
+__global__ void __launch_bounds__(64)
+interpolate_waypoints_kernel(int E, int P, int L, const T *__restrict__ paths, const int *__restrict__ best_idx,
+                             T res, int Wmax, T *__restrict__ wp_out, int *__restrict__ wcount)
+{
+    __shared__ int s_off[65];
+    const int e = blockIdx.x, i = threadIdx.x;
+    const int b = best_idx[e];
+    if (b < 0 || b >= P) { if (i == 0) wcount[e] = 0; return; }
+    const T *x = paths + ((int64_t)e * P + b) * 3 * L, *y = x + L;
+    for (int base = 0; base < L - 1; base += 64) {      // L - 1 <= 64 segments per trip
+        const int sgi = base + i;
+        int cnt = 0;
+        T dx = 0, dy = 0, dist = 0;
+        if (sgi < L - 1) {
+            dx = x[sgi + 1] - x[sgi]; dy = y[sgi + 1] - y[sgi];
+            dist = Lib<T>::sqrt(dx * dx + dy * dy);
+            const int num = (int)floor(dist / res) - 1;                          // :411
+            cnt = 1 + (num > 0 ? num : 0);
+        }
+        s_off[i + 1] = cnt;
+        if (i == 0) s_off[0] = base == 0 ? 0 : s_off[0];
+        __syncthreads();
+        if (i == 0) for (int j = 0; j < 64; ++j) s_off[j + 1] += s_off[j];
+        __syncthreads();
+        const int total_after = s_off[64];
+        if (sgi < L - 1 && total_after + 1 <= Wmax) {
+            T *o = wp_out + ((int64_t)e * Wmax + s_off[i]) * 2;
+            o[0] = x[sgi]; o[1] = y[sgi];                                        // :407
+            const T ux = dx / dist, uy = dy / dist;                              // :413
+            for (int j = 0; j < cnt - 1; ++j) {
+                const T f = res * (T)(j + 1);                                    // :416
+                o[2 * (j + 1)] = x[sgi] + f * ux;
+                o[2 * (j + 1) + 1] = y[sgi] + f * uy;
+            }
+        }
+        __syncthreads();
+        if (i == 0) s_off[0] = total_after;
+        __syncthreads();
+    }
+    if (i == 0) {
+        const int n = s_off[0];
+        if (n + 1 <= Wmax) {
+            wp_out[((int64_t)e * Wmax + n) * 2] = x[L - 1];                      // :419
+            wp_out[((int64_t)e * Wmax + n) * 2 + 1] = y[L - 1];
+            wcount[e] = n + 1;
+        } else {
+            wcount[e] = 0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- launchers ---------
 
 template <typename T>
@@ -759,6 +869,31 @@ hipError_t launch_select_best_path(const SelectArgs<T> &a, hipStream_t st)
     return hipGetLastError();
 }
 
+template <typename T>
+hipError_t launch_plan_lattice(const LatticeArgs<T> &a, hipStream_t st)
+{
+    if (a.E <= 0) return hipSuccess;
+    hipLaunchKernelGGL((lattice_index_kernel<T>), dim3((unsigned)((a.E + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       a.E, a.px, a.py, a.nwp, a.ego, (T)a.lookahead, a.closest_idx, a.goal_idx, a.closest_len);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t lanes = (int64_t)a.E * a.P;
+    hipLaunchKernelGGL((lattice_paths_kernel<T>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       st, a.E, a.P, a.px, a.py, a.nwp, a.ego, a.goal_idx, (T)a.goal_v, (T)a.path_offset,
+                       a.params_in, a.goal_set, a.params, a.paths, a.validity, a.cost);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, const int *best_idx, double res,
+                                        int Wmax, T *wp_out, int *wcount, hipStream_t st)
+{
+    if (E <= 0) return hipSuccess;
+    hipLaunchKernelGGL((interpolate_waypoints_kernel<T>), dim3((unsigned)E), dim3(64), 0, st, E, P, L, paths,
+                       best_idx, (T)res, Wmax, wp_out, wcount);
+    return hipGetLastError();
+}
+
 #define VDYN_INSTANTIATE(T)                                                                          \
     template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
@@ -768,7 +903,10 @@ hipError_t launch_select_best_path(const SelectArgs<T> &a, hipStream_t st)
     template hipError_t launch_closed_loop<T>(const VdynParams &, const VdynCtrlGains &,             \
                                               const ClosedLoopArgs<T> &, hipStream_t);               \
     template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t); \
-    template hipError_t launch_select_best_path<T>(const SelectArgs<T> &, hipStream_t);
+    template hipError_t launch_select_best_path<T>(const SelectArgs<T> &, hipStream_t);             \
+    template hipError_t launch_plan_lattice<T>(const LatticeArgs<T> &, hipStream_t);                 \
+    template hipError_t launch_interpolate_waypoints<T>(int, int, int, const T *, const int *, double, int, T *, \
+                                                        int *, hipStream_t);
 VDYN_INSTANTIATE(float)
 VDYN_INSTANTIATE(double)
 

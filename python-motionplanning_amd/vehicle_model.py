@@ -488,6 +488,48 @@ class VehicleModel:
             _vp(free), _vp(bi), _vp(bs), *be.stream_args())
         return free, bi, bs
 
+    # ------------------------------------------------- lattice generation
+    def plan_lattice(self, px, py, ego, goal_v, lookahead=30.0, num_paths=7, path_offset=2.0, spiral_params=None):
+        """One planning cycle of LocalPlanner.MotionPlanner up to the transformed lattice
+        (local_planner.py:362-368) for E egos: ``px, py [nwp]`` global path, ``ego [3][E]`` rows
+        x, y, yaw.  Returns a dict: ``closest_index [E]``, ``goal_index [E]``, ``closest_len [E]``,
+        ``goal_set [E][P][4]``, ``params [E][P][3]``, ``paths [E][P][3][49]``, ``validity [E][P]``,
+        ``cost [E][P]``.  ``spiral_params [E][P][3]`` skips the optimiser.  Defaults: drive.py:21,24,35."""
+        be = _Backend(ego)
+        eg = be.inp(ego)
+        if eg.ndim != 2 or eg.shape[0] != 3:
+            raise ValueError("ego must be [3][E] (x, y, yaw)")
+        E, P = int(eg.shape[1]), int(num_paths)
+        pxx, pyy = be.inp(px), be.inp(py)
+        if pxx.ndim != 1 or pxx.shape != pyy.shape or pxx.shape[0] < 2:
+            raise ValueError("px, py must be 1-D of equal length >= 2")
+        if P < 1:
+            raise ValueError("num_paths must be >= 1")
+        pin = None if spiral_params is None else be.inp(spiral_params, shape=(E, P, 3))
+        ci, gi, val = be.out(E, int32=True), be.out(E, int32=True), be.out(E, P, int32=True)
+        cl, gs, pr, pa, co = be.out(E), be.out(E, P, 4), be.out(E, P, 3), be.out(E, P, 3, 49), be.out(E, P)
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_plan_lattice_{be.suffix}_{be.kind}", E, _vp(pxx), _vp(pyy), int(pxx.shape[0]), _vp(eg),
+            float(goal_v), float(lookahead), P, float(path_offset), _vp(pin), _vp(ci), _vp(gi), _vp(cl), _vp(gs),
+            _vp(pr), _vp(pa), _vp(val), _vp(co), *be.stream_args())
+        return dict(closest_index=ci, goal_index=gi, closest_len=cl, goal_set=gs, params=pr, paths=pa,
+                    validity=val, cost=co)
+
+    def interpolate_waypoints(self, paths, best_idx, res=0.01, Wmax=4096):
+        """local_planner.py:395-419 for E egos: ``paths [E][P][3][L]``, ``best_idx [E]`` ->
+        ``wp [E][Wmax][2]``, ``wcount [E]``: the tables ``closed_loop`` / ``controller_update`` take."""
+        be = _Backend(paths)
+        pa = be.inp(paths)
+        if pa.ndim != 4 or pa.shape[2] != 3 or pa.shape[3] < 2:
+            raise ValueError("paths must be [E][P][3][L]")
+        E, P, _, L = (int(v) for v in pa.shape)
+        bi = be.inp(best_idx, shape=(E,), int32=True)
+        wp, wc = be.out(E, int(Wmax), 2), be.out(E, int32=True)
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_interpolate_waypoints_{be.suffix}_{be.kind}", E, P, L, _vp(pa), _vp(bi), float(res), int(Wmax),
+            _vp(wp), _vp(wc), *be.stream_args())
+        return wp, wc
+
     def synchronize(self, device=None):
         """Wait for the default stream of `device` (NumPy calls are already synchronous)."""
         d = self.device if device is None else device

@@ -595,3 +595,64 @@ def test_wheel_parallel_kernel_matches_oracle_and_lane_kernel(pkg, oracle, workl
     assert np.array_equal(auto.rollout(s0, ctrl), q)
     big0, btab, bpid = workloads.config3(40000, 20)
     assert np.array_equal(auto.rollout(big0, btab, path_id=bpid), vm(1e-3, 1).rollout(big0, btab, path_id=bpid))
+
+
+# ---- "next" row 3: lattice generation -------------------------------------------------------------
+def test_g11_lattice_generation(gpu_vm, oracle):
+    """3 planning cycles of the reference: indices exact; goal states / sampled + transformed
+    spirals at rounding level when fed the reference's own optimum; with the device optimiser
+    (projected Levenberg-Marquardt instead of SciPy's L-BFGS-B) the objective is at least as low
+    as SciPy's and the paths agree to the optimisers' tolerance; then interpolation (G9 tables)."""
+    g = load_golden("g11_lattice.npz")
+    g9 = load_golden("g9_closed_loop_controls.npz")
+    g10 = load_golden("g10_collision_select.npz")
+    look, P, off, res = g["consts"]
+    vm = gpu_vm(1e-3)
+    ego = g["ego"][:, :3].T.copy()                                          # [3][E = 3]
+    o = vm.plan_lattice(g["px"], g["py"], ego, float(g["target_vel"]), look, int(P), off,
+                        spiral_params=g["opt_x"])
+    assert np.array_equal(o["closest_index"], g["closest_index"]) and np.array_equal(o["goal_index"], g["goal_index"])
+    assert np.abs(o["closest_len"] - g["closest_len"]).max() <= 1e-13
+    assert np.abs(o["goal_set"] - g["goal_set"]).max() <= 1e-11
+    assert np.abs(o["paths"] - g["transformed"]).max() <= 1e-11
+    assert np.array_equal(o["validity"].astype(bool), g["validity"])
+    assert np.abs(o["cost"] - g["opt_fun"]).max() <= 1e-10
+    full = vm.plan_lattice(g["px"], g["py"], ego, float(g["target_vel"]), look, int(P), off)
+    assert (full["cost"] <= g["opt_fun"] * (1 + 1e-9) + 1e-12).all(), "device optimum must not be worse than SciPy's"
+    assert np.abs(full["params"] - g["opt_x"]).max() <= 2e-4
+    assert np.abs(full["paths"] - g["transformed"]).max() <= 2e-3
+    assert np.array_equal(full["validity"].astype(bool), g["validity"])
+    wp, wc = vm.interpolate_waypoints(o["paths"], g10["best_index"][:3].astype(np.int32), float(res), 4096)
+    for f in range(3):
+        assert wc[f] == g9["waypoint_count"][f]
+        assert np.abs(wp[f, :wc[f]] - g9["waypoints"][f, :wc[f], :2]).max() <= 1e-11
+    wp2, wc2 = vm.interpolate_waypoints(o["paths"], np.array([-1, 2, 6], np.int32), float(res), 1000)
+    assert wc2[0] == 0 and wc2[1] == 0 and wc2[2] == 0                  # none selected / table too small
+
+
+def test_lattice_optimiser_vs_scipy_on_seeded_goals(gpu_vm, oracle):
+    """48 seeded goal states optimised by the reference (G11 direct_*), and 2000 egos spread along
+    the global path against the oracle's SciPy-driven plan on a sample of them."""
+    g = load_golden("g11_lattice.npz")
+    vm = gpu_vm(1e-3)
+    # a straight global path along +x makes goal (xf, yf, tf) = (lookahead-ish, offset, 0); instead
+    # drive the kernel's optimiser directly through egos placed so that the goal set hits the seeds
+    rng = np.random.default_rng(5)
+    E = 2000
+    idx = rng.integers(20, len(g["px"]) - 800, E)
+    yaw = np.arctan2(g["py"][idx + 1] - g["py"][idx], g["px"][idx + 1] - g["px"][idx]) + rng.normal(0, 0.08, E)
+    ego = np.stack([g["px"][idx] + rng.normal(0, 0.8, E), g["py"][idx] + rng.normal(0, 0.8, E), yaw])
+    dev = vm.plan_lattice(g["px"], g["py"], ego, 25.0)
+    assert np.isfinite(dev["paths"]).all() and dev["validity"].mean() > 0.9
+    worst_p = worst_path = 0.0
+    for e in range(0, E, 100):
+        o = oracle.plan_paths(g["px"], g["py"], ego[:, e], 25.0)
+        assert o["closest_index"] == dev["closest_index"][e] and o["goal_index"] == dev["goal_index"][e]
+        assert np.abs(o["goal_set"] - dev["goal_set"][e]).max() <= 1e-10
+        Jo = np.array([oracle.spiral_objective(o["params"][k], *o["goal_set"][k, :3])[0] for k in range(7)])
+        assert (dev["cost"][e] <= Jo * (1 + 1e-8) + 1e-12).all()
+        worst_p = max(worst_p, np.abs(dev["params"][e] - o["params"]).max())
+        worst_path = max(worst_path, np.abs(dev["paths"][e] - o["paths"]).max())
+        assert np.array_equal(dev["validity"][e].astype(bool), o["validity"])
+    print(f"\n  lattice: max |params - scipy| {worst_p:.2e}, max |path - scipy| {worst_path:.2e} m")
+    assert worst_p <= 1e-3 and worst_path <= 5e-3
