@@ -297,6 +297,17 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = (time.perf_counter() - t0) / 300
     ex["dropin_single_vehicle_step_f64"] = {"us_per_call": t * 1e6, "steps_per_s": 1.0 / t,
                                             "reference_numpy_us_per_call": 247.7}
+    # lattice generation: 9363 egos x 7 spirals, device optimiser, fp64
+    Ego = 9363
+    th = np.linspace(0.0, 2 * np.pi, 4000, endpoint=False)
+    gpx, gpy = 200.0 * np.cos(th), 200.0 * np.sin(th)                       # a 200 m circle as global path
+    k = np.random.default_rng(20244).integers(0, 4000, Ego)
+    ego = np.stack([gpx[k] + 0.5, gpy[k] - 0.5, th[k] + np.pi / 2 + 0.05])
+    lat_in = [torch.from_numpy(a).to(dev) for a in (gpx, gpy, ego)]
+    run_lat = lambda: vm.plan_lattice(lat_in[0], lat_in[1], lat_in[2], 25.0)
+    run_lat()
+    t = timed_launches(run_lat, 3, torch)
+    ex["plan_lattice_9363x7_f64"] = {"ms": t * 1e3, "spirals_per_s": Ego * 7 / t, "planning_cycles_per_s": Ego / t}
     # the same workload through the HOST-pointer ABI (staging copies over PCIe included)
     s0_h, pid_h = s0.cpu().numpy(), pid.cpu().numpy()
     vm.rollout(s0_h, tab, path_id=pid_h)

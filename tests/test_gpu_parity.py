@@ -656,3 +656,43 @@ def test_lattice_optimiser_vs_scipy_on_seeded_goals(gpu_vm, oracle):
         assert np.array_equal(dev["validity"][e].astype(bool), o["validity"])
     print(f"\n  lattice: max |params - scipy| {worst_p:.2e}, max |path - scipy| {worst_path:.2e} m")
     assert worst_p <= 1e-3 and worst_path <= 5e-3
+
+
+def test_three_frames_of_car_drive_entirely_on_device(gpu_vm, pkg):
+    """The reference's whole frame loop (drive.py:112-154) with every stage on the GPU: plan the
+    lattice (device optimiser), check collisions and pick the best path, re-interpolate it into
+    the Stanley table, then 100 sub-steps of controllers + RK4 -- three frames chained, compared
+    with the trajectory the reference's own Car.drive produced (G4 / G9)."""
+    g4 = load_golden("g4_closed_loop_world.npz")
+    g9 = load_golden("g9_closed_loop_controls.npz")
+    g10 = load_golden("g10_collision_select.npz")
+    g11 = load_golden("g11_lattice.npz")
+    dt = float(g9["dt"])
+    vm = gpu_vm(dt)
+    gains = _g9_gains(pkg, g9)
+    px, py = g11["px"], g11["py"]
+    s = np.concatenate([g9["state"], g9["ax_ay_prev"]])[:, None]
+    c = np.array([g9["x_del"], g9["total_vel_error"], g9["prev_vel"], g9["target_vel"], 0.0, 0.0])[:, None]
+    for f in range(3):
+        ego = s[[8, 9, 7]]                                                   # x, y, yaw  [3][1]
+        lat = vm.plan_lattice(px, py, ego, float(g9["target_vel"]))
+        assert lat["goal_index"][0] == g11["goal_index"][f] and lat["validity"].all()
+        goal = np.array([[px[lat["goal_index"][0]]], [py[lat["goal_index"][0]]]])
+        free, best, score = vm.select_best_path(lat["paths"], g10["obstacles"][f], goal, g10["circle_offsets"],
+                                                g10["circle_radii"], float(g10["weight"]))
+        assert np.array_equal(free[0], g10["collision_free"][f])
+        # the two free paths (offsets -6 m and +6 m) mirror each other about the goal: their scores
+        # differ by less than either optimiser's tolerance, so only the score is comparable, and the
+        # chain continues on the path the reference happened to pick
+        _, _, ref_score = vm.select_best_path(g10["paths"][f:f + 1], g10["obstacles"][f], goal,
+                                              g10["circle_offsets"], g10["circle_radii"], float(g10["weight"]))
+        assert abs(score[0] - ref_score[0]) <= 1e-3 and free[0][best[0]]
+        best = g10["best_index"][f:f + 1].astype(np.int32)
+        wp, wc = vm.interpolate_waypoints(lat["paths"], best, 0.01, 4096)
+        assert wc[0] == g9["waypoint_count"][f]
+        s, c, log = vm.closed_loop(s, c, wp[:, :wc[0]], 100, gains=gains, phase=100 * f, log=True)
+        want = g9["rk4_log"][100 * f:100 * (f + 1)]
+        scale = np.maximum(np.abs(want[:, :10]).max(axis=0), 1e-3)
+        assert (np.abs(log[:, :10, 0] - want[:, :10]) <= 1e-6 * scale).all()
+        assert np.array_equal(log[::10, 14, 0], g9["stanley_out"][10 * f:10 * (f + 1), 1])
+    assert np.abs(s[:10, 0] - g4["state_update"][299]).max() <= 1e-6 * np.abs(g4["state_update"][299]).max()
