@@ -246,8 +246,15 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
 
 // Config-5 MPC selection.  Block = one ego; lanes stride over the C shared
 // candidates; cost and (min, argmin) never leave the chip until the final pair.
+// Workgroup size and occupancy target.  fp32: 512 threads at 4 waves per SIMD (128 registers;
+// the step needs 135, the 16-byte spill costs less than the lost wave: 0.65 vs 0.70 ms on
+// config 5).  fp64: 256 threads, one wave per SIMD with the full register file (no spill;
+// at 128 registers the fp64 step spilled 700 bytes per lane).
+template <typename T> constexpr int mpc_block_max() { return sizeof(T) == 4 ? 512 : 256; }
+template <typename T> constexpr int mpc_waves_per_simd() { return sizeof(T) == 4 ? 4 : 1; }
+
 template <typename T, bool CS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(mpc_block_max<T>(), mpc_waves_per_simd<T>())
 mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego,
                   const T *__restrict__ cand, const T *__restrict__ goal, T h, T w_delta,
                   T *__restrict__ best_cost, int *__restrict__ best_idx, T *__restrict__ cost_all)
@@ -781,7 +788,7 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
     if (E <= 0) return hipSuccess;
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
     int block = ((C + 63) / 64) * 64;
-    block = std::max(64, std::min(block, 1024));
+    block = std::max(64, std::min(block, mpc_block_max<T>()));
     if (shape_factors_small(p))
         hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
                            C, H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);

@@ -27,25 +27,46 @@ namespace vdyn {
 constexpr int kSpiralPoints = 49;  // x, y entries of a sampled spiral (np.linspace's 50 minus the origin)
 
 // ---- local_planner.py:25-52: '<=' on the sqrt distances -> the LAST of equal minima wins ----
-template <typename T>
-__device__ __forceinline__ void closest_index(const T *__restrict__ px, const T *__restrict__ py, int n, T ex,
-                                              T ey, int &idx, T &len)
+// Same structure as the Stanley scan (vdyn_controls.hpp): squared distances in an unrolled,
+// branch-free loop; a sticky flag marks a candidate a few ulp ABOVE the running minimum (its
+// rounded root may still tie, and the reference would then move to the later index); flagged
+// lanes repeat the scan comparing the roots themselves.
+template <typename T, bool EXACT>
+__device__ __forceinline__ void closest_scan(const T *__restrict__ px, const T *__restrict__ py, int n, T ex, T ey,
+                                             T &best_d2, int &best_i, bool &ambiguous)
 {
     using L = Lib<T>;
-    T best_d2 = T(INFINITY);
-    int best_i = 0;
+    best_d2 = T(INFINITY);
+    best_i = 0;
+    ambiguous = false;
     const T band = T(2) - L::kTieBand;  // 1 + 16 ulp
+#pragma unroll 8
     for (int i = 0; i < n; ++i) {
         const T dx = px[i] - ex, dy = py[i] - ey;
         const T d2 = dx * dx + dy * dy;
         bool take = d2 <= best_d2;
-        // d2 a few ulp ABOVE the running minimum may still tie after the square root
-        if (!take && d2 <= best_d2 * band) take = L::sqrt(d2) <= L::sqrt(best_d2);
+        const bool close = !take && d2 <= best_d2 * band;
+        if (EXACT) {
+            if (close) take = L::sqrt(d2) <= L::sqrt(best_d2);
+        } else {
+            ambiguous = ambiguous || close;
+        }
         best_d2 = take ? d2 : best_d2;
         best_i = take ? i : best_i;
     }
-    idx = best_i;
-    len = L::sqrt(best_d2);
+}
+
+template <typename T>
+__device__ __forceinline__ void closest_index(const T *__restrict__ px, const T *__restrict__ py, int n, T ex,
+                                              T ey, int &idx, T &len)
+{
+    T best_d2;
+    bool amb;
+    closest_scan<T, false>(px, py, n, ex, ey, best_d2, idx, amb);
+    if (__builtin_expect(__any(amb) != 0, 0)) {
+        if (amb) closest_scan<T, true>(px, py, n, ex, ey, best_d2, idx, amb);
+    }
+    len = Lib<T>::sqrt(best_d2);
 }
 
 // ---- local_planner.py:85-152 ----
