@@ -58,10 +58,13 @@ __device__ __forceinline__ T wrap_pi(T e)
 // (optionally) the table of segment lengths seg[i] = |wp[i] - wp[i-1]| (seg[0] unused) that
 // the workgroup computed once, so that the lookahead walk does not take a sqrt per lane
 // per waypoint.
+constexpr int kWpBlock = 32;  // waypoints per bounding circle
+
 template <typename T>
 struct Waypoints {
-    const T *base;  // this lane's table: [W][2]
-    const T *seg;   // nullable: [W] segment lengths of the same table
+    const T *base;    // this lane's table: [W][2]
+    const T *seg;     // nullable: [W] segment lengths of the same table
+    const T *bounds;  // nullable: [ceil(W / 32)][4] = centre x, y, radius (inflated), unused
     int W;
     __device__ __forceinline__ void get(int i, T &x, T &y) const
     {
@@ -111,6 +114,60 @@ __device__ __forceinline__ void nearest_waypoint(const Waypoints<T> &wp, T x, T 
     }
 }
 
+// One block of the scan above (waypoints [lo, hi)), continuing a running minimum.
+template <typename T, bool EXACT>
+__device__ __forceinline__ void nearest_in_range(const Waypoints<T> &wp, int lo, int hi, T x, T y, T &best_d2,
+                                                 int &best_i, bool &ambiguous)
+{
+    using L = Lib<T>;
+#pragma unroll 8
+    for (int i = lo; i < hi; ++i) {
+        T wx, wy;
+        wp.get(i, wx, wy);
+        const T dx = wx - x, dy = wy - y;
+        const T d2 = dx * dx + dy * dy;
+        bool better = d2 < best_d2;
+        const bool close = better && d2 >= best_d2 * L::kTieBand;
+        if (EXACT) {
+            if (close) better = L::sqrt(d2) < L::sqrt(best_d2);
+        } else {
+            ambiguous = ambiguous || close;
+        }
+        best_d2 = better ? d2 : best_d2;
+        best_i = better ? i : best_i;
+    }
+}
+
+// The same global search, exactly, with most of the table skipped: every 32 consecutive
+// waypoints carry a bounding circle (centre c, radius r >= every member's distance to c), and a
+// block whose nearest possible member, |q - c| - r, is farther than the running minimum can hold
+// neither the minimum nor a tie with it.  Blocks are visited in order, so "first minimum wins"
+// is preserved; a wave descends into a block when any of its lanes needs it.
+template <typename T, bool EXACT>
+__device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, T x, T y, T &best_d2, int &best_i,
+                                                        bool &ambiguous)
+{
+    using L = Lib<T>;
+    best_d2 = T(INFINITY);
+    best_i = 0;
+    ambiguous = false;
+    T best_d = T(INFINITY);
+    const int nb = (wp.W + kWpBlock - 1) / kWpBlock;
+    for (int b = 0; b < nb; ++b) {
+        const T cx = wp.bounds[4 * b], cy = wp.bounds[4 * b + 1], r = wp.bounds[4 * b + 2];
+        const T ex = cx - x, ey = cy - y;
+        const T dq = L::sqrt(ex * ex + ey * ey);
+        const bool need = !(dq * T(0.999999) - r > best_d);       // when in doubt, scan
+        if (__any(need)) {
+            if (need) {
+                nearest_in_range<T, EXACT>(wp, b * kWpBlock, min((b + 1) * kWpBlock, wp.W), x, y, best_d2, best_i,
+                                           ambiguous);
+                best_d = L::sqrt(best_d2);
+            }
+        }
+    }
+}
+
 // stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
 template <typename T>
 __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Waypoints<T> &wp, T x, T y, T yaw,
@@ -120,9 +177,16 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
     T best_d2;
     int best_i;
     bool amb;
-    nearest_waypoint<T, false>(wp, x, y, best_d2, best_i, amb);
-    if (__builtin_expect(__any(amb) != 0, 0)) {          // wave-uniform, practically never taken
-        if (amb) nearest_waypoint<T, true>(wp, x, y, best_d2, best_i, amb);
+    if (wp.bounds != nullptr) {
+        nearest_waypoint_pruned<T, false>(wp, x, y, best_d2, best_i, amb);
+        if (__builtin_expect(__any(amb) != 0, 0)) {      // wave-uniform, practically never taken
+            if (amb) nearest_waypoint_pruned<T, true>(wp, x, y, best_d2, best_i, amb);
+        }
+    } else {
+        nearest_waypoint<T, false>(wp, x, y, best_d2, best_i, amb);
+        if (__builtin_expect(__any(amb) != 0, 0)) {
+            if (amb) nearest_waypoint<T, true>(wp, x, y, best_d2, best_i, amb);
+        }
     }
     // :68-76 walk forward until the accumulated arc length reaches the lookahead distance
     T total = L::sqrt(best_d2);

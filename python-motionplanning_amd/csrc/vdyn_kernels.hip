@@ -332,8 +332,10 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     // padded by one entry so that the tables of different paths start on different banks
     // (lanes of one wave follow different paths and read the same waypoint index together)
     const int wstride = Wmax + 1;
+    const int nbmax = (Wmax + kWpBlock - 1) / kWpBlock;
     T *lds_wp = reinterpret_cast<T *>(smem_raw);
     T *lds_seg = lds_wp + (int64_t)Pn * wstride * 2;
+    T *lds_bnd = lds_seg + (int64_t)Pn * wstride;      // [P][nbmax][4] bounding circles of 32-waypoint blocks
     if (WPLDS) {
         for (int i = threadIdx.x; i < Pn * Wmax; i += kBlock) {
             const int p = i / Wmax, j = i - p * Wmax;
@@ -342,6 +344,29 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
             lds_wp[2 * (p * wstride + j) + 1] = wy;
             // segment lengths, once per workgroup instead of once per lane per walk step
             lds_seg[p * wstride + j] = j == 0 ? T(0) : segment_length<T>(wp[2 * (int64_t)i - 2], wp[2 * (int64_t)i - 1], wx, wy);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Pn * nbmax; i += kBlock) {
+            const int p = i / nbmax, b = i - p * nbmax;
+            const int W = min(max(wcount[p], 1), Wmax);
+            const int lo = b * kWpBlock, hi = min(lo + kWpBlock, W);
+            T x0 = T(INFINITY), x1 = -T(INFINITY), y0 = T(INFINITY), y1 = -T(INFINITY);
+            for (int j = lo; j < hi; ++j) {
+                const T wx = lds_wp[2 * (p * wstride + j)], wy = lds_wp[2 * (p * wstride + j) + 1];
+                x0 = wx < x0 ? wx : x0; x1 = wx > x1 ? wx : x1;
+                y0 = wy < y0 ? wy : y0; y1 = wy > y1 ? wy : y1;
+            }
+            const T cx = T(0.5) * (x0 + x1), cy = T(0.5) * (y0 + y1);
+            T r2 = T(0);
+            for (int j = lo; j < hi; ++j) {
+                const T dx = lds_wp[2 * (p * wstride + j)] - cx, dy = lds_wp[2 * (p * wstride + j) + 1] - cy;
+                const T d2 = dx * dx + dy * dy;
+                r2 = d2 > r2 ? d2 : r2;
+            }
+            T *o = lds_bnd + 4 * (int64_t)i;
+            o[0] = cx; o[1] = cy;
+            o[2] = Lib<T>::sqrt(r2) * T(1.00001) + T(1e-30);     // never smaller than the true radius
+            o[3] = T(0);
         }
         __syncthreads();
     }
@@ -368,6 +393,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     Waypoints<T> w;
     w.base = WPLDS ? lds_wp + (int64_t)pid * wstride * 2 : wp + (int64_t)pid * Wmax * 2;
     w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : nullptr;
+    w.bounds = WPLDS ? lds_bnd + (int64_t)pid * nbmax * 4 : nullptr;
     w.W = min(max(wcount[pid], 1), Wmax);
 
     for (int t = 0; t < H; ++t) {
@@ -445,6 +471,7 @@ controller_kernel(CtrlGains<T> G, int64_t n, const T *__restrict__ state, const 
     Waypoints<T> w;
     w.base = wp + (int64_t)pid * Wmax * 2;
     w.seg = nullptr;
+    w.bounds = nullptr;
     w.W = min(max(wcount[pid], 1), Wmax);
     T steer;
     controller_update<T>(G, w, s, h, c, steer);
@@ -818,7 +845,8 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
     const CtrlGains<T> G = make_gains<T>(g);
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
-    const size_t wp_bytes = (size_t)a.P * (a.Wmax + 1) * 3 * sizeof(T);   // padded (x, y) pairs + segment lengths
+    // padded (x, y) pairs + segment lengths + one bounding circle per 32 waypoints
+    const size_t wp_bytes = ((size_t)a.P * (a.Wmax + 1) * 3 + (size_t)a.P * ((a.Wmax + kWpBlock - 1) / kWpBlock) * 4) * sizeof(T);
     // gfx950 has 160 KiB of LDS per CU; a workgroup may take all of it (one workgroup per
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
     const bool lds = wp_bytes <= 152 * 1024;
