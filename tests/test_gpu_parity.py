@@ -729,3 +729,52 @@ def test_car_drive_mirror_against_oracle_frames(gpu_vm, pkg, oracle):
         assert np.abs(rows[:, 21] - log[:, 12, 0]).max() <= 1e-7 and np.abs(rows[:, 44] - log[:, 15, 0]).max() <= 1e-4
         assert abs(rows[0, 0] - 100 * f * dt) <= 1e-15
     assert len(car.x_del) == 31 and car.target_id == int(log[-1, 14, 0])
+
+
+def test_widened_entry_points_argument_errors_and_empty_batches(gpu_vm, pkg):
+    """Error behaviour of the controller / selection / lattice entry points: bad sizes and null
+    buffers come back as VDYN_ERR_ARG (VdynError) or ValueError from the shim, never as a fault;
+    empty batches are no-ops."""
+    vm = gpu_vm(1e-3)
+    h = vm._handle(0)
+    g = pkg._lib.default_ctrl_gains()
+    import ctypes as C
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_closed_loop_f64_host", C.byref(g), 4, 10, 0, 0, None, None, None, 8, None, None, 1, 1e-3,
+               None, None, None, None)                                   # ctrl_every = 0
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_closed_loop_f64_host", C.byref(g), 4, 10, 10, 0, None, None, None, 8, None, None, 1, 1e-3,
+               None, None, None, None)                                   # null buffers
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_select_best_path_f64_host", 2, 65, 10, None, None, 0, 0, None, None, 3, None, 1.0, None, None,
+               None, None)                                               # more than 64 paths
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_plan_lattice_f64_host", 3, None, None, 1, None, 25.0, 30.0, 7, 2.0, None, None, None, None,
+               None, None, None, None, None)                             # nwp < 2
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_interpolate_waypoints_f64_host", 1, 7, 49, None, None, 0.0, 100, None, None)   # res <= 0
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_set_option", 1, 3)
+    with pytest.raises(ValueError):
+        vm.closed_loop(np.zeros((12, 2)), np.zeros((6, 2)), np.zeros((1, 5, 3)), 10)      # waypoints not (x, y)
+    with pytest.raises(ValueError):
+        vm.closed_loop(np.zeros((12, 2)), np.zeros((6, 2)), np.zeros((1, 5, 2)), 10, wcount=[9])
+    with pytest.raises(ValueError):
+        vm.select_best_path(np.zeros((1, 3, 2, 9)), np.zeros((4, 2)), np.zeros((2, 1)))
+    with pytest.raises(ValueError):
+        vm.plan_lattice(np.zeros(5), np.zeros(4), np.zeros((3, 1)), 25.0)
+    with pytest.raises(ValueError):
+        pkg.VehicleModel(1.0, 0.7, 1e-3, lanes_per_rollout=2)
+    # empty batches
+    t, c = vm.closed_loop(np.zeros((12, 0)), np.zeros((6, 0)), np.zeros((1, 5, 2)), 10)
+    assert t.shape == (12, 0) and c.shape == (6, 0)
+    f, b, s = vm.select_best_path(np.zeros((0, 7, 3, 49)), np.zeros((4, 2)), np.zeros((2, 0)))
+    assert f.shape == (0, 7) and b.shape == (0,)
+    lat = vm.plan_lattice(np.arange(10.0), np.zeros(10), np.zeros((3, 0)), 25.0)
+    assert lat["paths"].shape == (0, 7, 3, 49)
+    # no obstacles at all: every path is free, the one ending nearest the goal wins
+    paths = np.zeros((1, 3, 3, 5))
+    paths[0, :, 0] = np.linspace(0, 4, 5)
+    paths[0, :, 1] = np.array([[-1.0], [0.2], [1.0]])
+    f, b, s = vm.select_best_path(paths, np.zeros((0, 2)), np.array([[4.0], [0.0]]))
+    assert f.all() and b[0] == 1 and abs(s[0] - 0.2) < 1e-12
