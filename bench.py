@@ -308,6 +308,34 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     run_lat()
     t = timed_launches(run_lat, 3, torch)
     ex["plan_lattice_9363x7_f64"] = {"ms": t * 1e3, "spirals_per_s": Ego * 7 / t, "planning_cycles_per_s": Ego / t}
+    # one whole frame of the reference's Car.drive (drive.py:112-154) for a fleet, device to device:
+    # plan the lattice, check collisions / pick the best path, re-interpolate it into each ego's
+    # Stanley table (1 cm spacing), then 100 sub-steps of controllers + RK4 against that table
+    Ef = 4096
+    egof = lat_in[2][:, :Ef].contiguous()
+    obst = torch.from_numpy(np.stack([gpx[::97] * 1.02, gpy[::97] * 1.02], axis=1)).to(dev)   # posts 4 m outside the lane
+    s_f = np.zeros((12, Ef))
+    s_f[0], s_f[3:7] = 25.0, 25.0 / W.DEFAULT_RW
+    s_f[[8, 9, 7]] = ego[:, :Ef]
+    c_f = np.zeros((6, Ef))
+    c_f[2], c_f[3] = 25.0, 25.0
+    s_f, c_f = torch.from_numpy(s_f).to(dev), torch.from_numpy(c_f).to(dev)
+    ids = torch.arange(Ef, dtype=torch.int32, device=dev)
+    vmf = type(vm)(2.906, np.deg2rad(30), 1e-4, device=vm.device)
+
+    def frame():
+        lat = vmf.plan_lattice(lat_in[0], lat_in[1], egof, 25.0)
+        gi = lat["goal_index"].long()
+        goal = torch.stack([lat_in[0][gi], lat_in[1][gi]])
+        _, best, _ = vmf.select_best_path(lat["paths"], obst, goal)
+        wp, wc = vmf.interpolate_waypoints(lat["paths"], best, 0.01, 4096)
+        return vmf.closed_loop(s_f, c_f, wp, 100, wcount=wc, path_id=ids)
+
+    term_f, _ = frame()
+    assert bool(torch.isfinite(term_f).all())
+    t = timed_launches(frame, 3, torch)
+    ex["full_frame_fleet_4096_f64"] = {"ms_per_frame": t * 1e3, "frames_per_s": Ef / t,
+                                       "reference_numpy_s_per_frame": 0.329}
     # the same workload through the HOST-pointer ABI (staging copies over PCIe included)
     s0_h, pid_h = s0.cpu().numpy(), pid.cpu().numpy()
     vm.rollout(s0_h, tab, path_id=pid_h)

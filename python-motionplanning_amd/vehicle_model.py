@@ -427,7 +427,11 @@ class VehicleModel:
         ``paths [E][P][3][L]`` (rows x, y, yaw: the reference's path lists); ``obstacles
         [M][2]`` shared or ``[E][M][2]``; ``goal [2][E]``.  ``collision_free [E][P]`` given:
         skip the check (select_best_path_index alone).  Returns ``collision_free [E][P]`` bool,
-        ``best_idx [E]`` (-1 = None) and ``best_score [E]``.  Defaults: drive.py:25-28."""
+        ``best_idx [E]`` (-1 = None) and ``best_score [E]``.  Defaults: drive.py:25-28.
+        torch CUDA tensors (e.g. ``plan_lattice``'s output) stay on the device."""
+        if _is_torch_cuda(paths):
+            return self._select_best_path_dev(paths, obstacles, goal, circle_offsets, circle_radii, weight,
+                                              collision_free)
         pa = np.ascontiguousarray(paths)
         dtype = pa.dtype if pa.dtype in (np.float32, np.float64) else np.dtype(np.float64)
         pa = pa.astype(dtype, copy=False)
@@ -457,6 +461,33 @@ class VehicleModel:
             f"vdyn_select_best_path_{_suffix(dtype)}_host", E, P, L, _vp(pa), _vp(ob), M, int(per_ego), _vp(off),
             _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(free), _vp(bi), _vp(bs))
         return free.astype(bool), bi, bs
+
+    def _select_best_path_dev(self, paths, obstacles, goal, circle_offsets, circle_radii, weight, collision_free):
+        be = _Backend(paths)
+        pa = be.inp(paths)
+        if pa.ndim != 4 or pa.shape[2] != 3:
+            raise ValueError("paths must be [E][P][3][L]")
+        E, P, _, L = (int(v) for v in pa.shape)
+        if P > 64:
+            raise ValueError("at most 64 paths per ego")
+        ob = be.inp(obstacles)
+        per_ego = ob.ndim == 3
+        if ob.shape[-1] != 2 or (per_ego and ob.shape[0] != E):
+            raise ValueError("obstacles must be [M][2] or [E][M][2]")
+        gl = be.inp(goal, shape=(2, E))
+        off = np.ascontiguousarray(circle_offsets, dtype=np.float64)
+        rad = np.ascontiguousarray(circle_radii, dtype=np.float64)
+        if off.shape != rad.shape or off.ndim != 1 or not 1 <= off.size <= 8:
+            raise ValueError("1..8 circle offsets / radii")
+        cin = None if collision_free is None else be.inp(collision_free, shape=(E, P), int32=True)
+        free, bi, bs = be.out(E, P, int32=True), be.out(E, int32=True), be.out(E)
+        esz, base = pa.element_size(), pa.data_ptr()
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_select_best_path_{be.suffix}_dev", E, P, L, C.c_void_p(base), C.c_void_p(base + L * esz),
+            C.c_void_p(base + 2 * L * esz), P * 3 * L, 3 * L, 1, _vp(ob), int(ob.shape[-2]), int(per_ego), _vp(off),
+            _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(free), _vp(bi), _vp(bs),
+            *be.stream_args())
+        return free.bool(), bi, bs
 
     def select_best_rollout(self, traj, paths_per_ego, obstacles, goal, circle_offsets=(-1.0, 1.0, 3.0),
                             circle_radii=(1.5, 1.5, 1.5), weight=10.0):

@@ -459,6 +459,12 @@ def test_g10_collision_and_selection(gpu_vm, pkg, oracle):
     _, _, obs = oracle.select_best_path(g["paths"], g["obstacles"], g["goal"].T.copy(), *args)
     ok = bi >= 0
     assert np.abs(bs[ok] - obs[ok]).max() <= 1e-9 and np.isinf(bs[~ok]).all()
+    import torch
+    dev = torch.device("cuda:0")
+    ft, bt, st = vm.select_best_path(torch.from_numpy(g["paths"]).to(dev), torch.from_numpy(g["obstacles"]).to(dev),
+                                     torch.from_numpy(g["goal"].T.copy()).to(dev), *args)   # device-pointer ABI
+    assert np.array_equal(ft.cpu().numpy(), free) and np.array_equal(bt.cpu().numpy(), bi)
+    assert np.array_equal(st.cpu().numpy(), bs)
     f32, b32, _ = vm.select_best_path(g["paths"].astype(np.float32), g["obstacles"].astype(np.float32),
                                       g["goal"].T.astype(np.float32), *args)
     assert (f32 == g["collision_free"]).mean() >= 0.99       # fp32 may flip a grazing contact
