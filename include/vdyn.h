@@ -158,6 +158,28 @@ int vdyn_rollout_f32_host(VdynHandle *h, int64_t n, int32_t H, const float *stat
                           double dt, const double *mu4, float *terminal, float *traj,
                           int32_t traj_stride);
 
+/* ---- rollout of a heterogeneous fleet ------------------------------------------------------
+ * As vdyn_rollout_*, but every rollout has its own vehicle class: classes [V] (HOST array of
+ * VdynParams, 1 <= V <= 256: different masses, geometry, Pacejka B / C ...), vehicle_id [n]
+ * (values in [0, V)).  The classes' constants are staged through LDS and each lane keeps its
+ * class's set in registers.  The handle's own parameters are not used.                        */
+int vdyn_rollout_fleet_f64_dev(VdynHandle *h, int64_t n, int32_t H, const double *state0, const double *ctrl,
+                               int k, int layout, const int32_t *path_id, int32_t P, const VdynParams *classes,
+                               int32_t V, const int32_t *vehicle_id, double dt, const double *mu4,
+                               double *terminal, double *traj, int32_t traj_stride, void *stream);
+int vdyn_rollout_fleet_f32_dev(VdynHandle *h, int64_t n, int32_t H, const float *state0, const float *ctrl,
+                               int k, int layout, const int32_t *path_id, int32_t P, const VdynParams *classes,
+                               int32_t V, const int32_t *vehicle_id, double dt, const double *mu4,
+                               float *terminal, float *traj, int32_t traj_stride, void *stream);
+int vdyn_rollout_fleet_f64_host(VdynHandle *h, int64_t n, int32_t H, const double *state0, const double *ctrl,
+                                int k, int layout, const int32_t *path_id, int32_t P, const VdynParams *classes,
+                                int32_t V, const int32_t *vehicle_id, double dt, const double *mu4,
+                                double *terminal, double *traj, int32_t traj_stride);
+int vdyn_rollout_fleet_f32_host(VdynHandle *h, int64_t n, int32_t H, const float *state0, const float *ctrl,
+                                int k, int layout, const int32_t *path_id, int32_t P, const VdynParams *classes,
+                                int32_t V, const int32_t *vehicle_id, double dt, const double *mu4,
+                                float *terminal, float *traj, int32_t traj_stride);
+
 /* ---- MPC selection (BASELINE config 5): E egos x C shared candidates x H steps -------
  * Rollout (e, c) starts from ego e and applies candidate c's k = 2 controls.
  *   cost[e][c] = ||(x_T, y_T) - goal_e||_2 + w_delta * sum_t delta[t][c]^2

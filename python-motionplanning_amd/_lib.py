@@ -93,6 +93,11 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_interpolate_waypoints_{_s}_dev"] = (_int, _iw + [_vp])
     SIGNATURES[f"vdyn_interpolate_waypoints_{_s}_host"] = (_int, _iw)
 
+for _s in ("f32", "f64"):
+    _rf = [_vp, _i64, _i32, _vp, _vp, _int, _int, _vp, _i32, _vp, _i32, _vp, _dbl, _vp, _vp, _vp, _i32]
+    SIGNATURES[f"vdyn_rollout_fleet_{_s}_dev"] = (_int, _rf + [_vp])
+    SIGNATURES[f"vdyn_rollout_fleet_{_s}_host"] = (_int, _rf)
+
 _lib = None
 
 

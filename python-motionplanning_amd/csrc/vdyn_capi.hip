@@ -20,6 +20,8 @@ struct VdynHandle {
     void *h_pinned = nullptr;
     size_t h_bytes = 0;
     int lanes_per_rollout = 1;      // VDYN_OPT_LANES_PER_ROLLOUT
+    void *d_fleet = nullptr;        // device copy of the per-class constants of the last fleet call
+    size_t d_fleet_bytes = 0;
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -157,6 +159,7 @@ void vdyn_destroy(VdynHandle *h)
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->h_mapped) (void)hipHostFree(h->h_mapped);
+    if (h->d_fleet) (void)hipFree(h->d_fleet);
     delete h;
 }
 
@@ -224,6 +227,40 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     const int64_t auto_max = sizeof(T) == 4 ? 32768 : 49152;
     b.lanes_per_rollout = h->lanes_per_rollout == 0 ? (a.n <= auto_max ? 4 : 1) : h->lanes_per_rollout;
     VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, b, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+// Fleet rollout: build the per-class table on the host, put it on the device (a small pageable
+// copy, enqueued on the caller's stream in front of the kernel), launch.
+template <typename T>
+int rollout_fleet_dev(VdynHandle *h, vdyn::RolloutArgs<T> a, const VdynParams *classes, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (a.n < 0 || a.H < 0 || (a.k != 2 && a.k != 12) ||
+        (a.layout != VDYN_CTRL_PER_ROLLOUT && a.layout != VDYN_CTRL_SHARED) || !std::isfinite(a.dt))
+        return rollout_dev<T>(h, a, stream, "rollout_fleet");
+    if (a.V < 1 || a.V > 256 || !classes) return h->fail(VDYN_ERR_ARG, "rollout_fleet: need 1 <= V <= 256 classes");
+    std::string why;
+    for (int v = 0; v < a.V; ++v)
+        if (!params_ok(&classes[v], &why)) return h->fail(VDYN_ERR_ARG, "rollout_fleet: class " + std::to_string(v) + ": " + why);
+    if (a.n == 0) return VDYN_OK;
+    if (!a.state0 || !a.terminal || !a.vehicle_id || (a.H > 0 && !a.ctrl) ||
+        (a.layout == VDYN_CTRL_SHARED && (!a.path_id || a.P <= 0)) || (a.traj && a.traj_stride <= 0))
+        return h->fail(VDYN_ERR_ARG, "rollout_fleet: null buffer or bad traj_stride");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(T) * (size_t)vdyn::fleet_table_len<T>(a.V);
+    if (bytes > h->d_fleet_bytes) {
+        if (h->d_fleet) { (void)hipFree(h->d_fleet); h->d_fleet = nullptr; h->d_fleet_bytes = 0; }
+        if (hipMalloc(&h->d_fleet, bytes) != hipSuccess) return h->fail(VDYN_ERR_OOM, "fleet table allocation failed");
+        h->d_fleet_bytes = bytes;
+    }
+    std::vector<T> tab(bytes / sizeof(T));
+    bool all_small = true;
+    vdyn::build_fleet_table<T>(classes, a.V, a.mu4, tab.data(), &all_small);
+    // pageable source: the runtime has consumed `tab` when this call returns
+    VDYN_HIP(h, hipMemcpyAsync(h->d_fleet, tab.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    a.fleet_tab = static_cast<const T *>(h->d_fleet);
+    VDYN_HIP(h, vdyn::launch_rollout_fleet<T>(a, all_small, (hipStream_t)stream));
     return VDYN_OK;
 }
 
@@ -328,6 +365,33 @@ private:
     bool mapped_ = false;
     char *host_ = nullptr, *dev_ = nullptr;
 };
+
+template <typename T>
+int rollout_fleet_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const VdynParams *classes)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (a.n <= 0 || a.H < 0 || (a.k != 2 && a.k != 12) || !a.state0 || !a.terminal || !a.vehicle_id ||
+        (a.H > 0 && !a.ctrl) || (a.layout != VDYN_CTRL_PER_ROLLOUT && a.layout != VDYN_CTRL_SHARED) ||
+        (a.layout == VDYN_CTRL_SHARED && (!a.path_id || a.P <= 0)) || (a.traj && a.traj_stride <= 0))
+        return a.n == 0 ? VDYN_OK : rollout_fleet_dev<T>(h, a, classes, h->stream);
+    const size_t e = sizeof(T) * (size_t)a.n;
+    const size_t ctrl_bytes = a.layout == VDYN_CTRL_PER_ROLLOUT ? (size_t)a.H * a.k * e
+                                                                : sizeof(T) * (size_t)a.P * a.H * a.k;
+    Stage s(h);
+    const size_t i0 = s.in(a.state0, 12 * e), i1 = s.in(a.ctrl, ctrl_bytes),
+                 i2 = s.in(a.path_id, a.layout == VDYN_CTRL_SHARED ? sizeof(int32_t) * (size_t)a.n : 0),
+                 i3 = s.in(a.vehicle_id, sizeof(int32_t) * (size_t)a.n);
+    const size_t o0 = s.out(a.terminal, 12 * e),
+                 o1 = s.out(a.traj, a.traj ? (size_t)(a.H / a.traj_stride) * 12 * e : 0);
+    int rc = s.upload();
+    if (rc) return rc;
+    a.state0 = s.dev<T>(i0, false); a.ctrl = s.dev<T>(i1, false); a.path_id = s.dev<int>(i2, false);
+    a.vehicle_id = s.dev<int>(i3, false);
+    a.terminal = s.dev<T>(o0, true); a.traj = s.dev<T>(o1, true);
+    rc = rollout_fleet_dev<T>(h, a, classes, h->stream);
+    if (rc) return rc;
+    return s.download();
+}
 
 template <typename T>
 int planar_model_host(VdynHandle *h, int64_t n, const T *state, const T *ctrl12, const T *acc_prev,
@@ -780,6 +844,28 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
                               goal, weight, collision_in, collision_free, best_idx, best_score);                       \
     }
 
+#define VDYN_DEFINE_FLEET_ABI(S, T)                                                                      \
+    extern "C" int vdyn_rollout_fleet_##S##_dev(                                                         \
+        VdynHandle *h, int64_t n, int32_t H, const T *state0, const T *ctrl, int k, int layout,          \
+        const int32_t *path_id, int32_t P, const VdynParams *classes, int32_t V, const int32_t *vehicle_id, \
+        double dt, const double *mu4, T *terminal, T *traj, int32_t traj_stride, void *stream)           \
+    {                                                                                                    \
+        vdyn::RolloutArgs<T> a = rollout_args<T>(n, H, state0, ctrl, k, layout, path_id, P, dt, mu4, terminal, \
+                                                 traj, traj_stride);                                     \
+        a.V = V; a.vehicle_id = vehicle_id;                                                              \
+        return rollout_fleet_dev<T>(h, a, classes, stream);                                              \
+    }                                                                                                    \
+    extern "C" int vdyn_rollout_fleet_##S##_host(                                                        \
+        VdynHandle *h, int64_t n, int32_t H, const T *state0, const T *ctrl, int k, int layout,          \
+        const int32_t *path_id, int32_t P, const VdynParams *classes, int32_t V, const int32_t *vehicle_id, \
+        double dt, const double *mu4, T *terminal, T *traj, int32_t traj_stride)                         \
+    {                                                                                                    \
+        vdyn::RolloutArgs<T> a = rollout_args<T>(n, H, state0, ctrl, k, layout, path_id, P, dt, mu4, terminal, \
+                                                 traj, traj_stride);                                     \
+        a.V = V; a.vehicle_id = vehicle_id;                                                              \
+        return rollout_fleet_host<T>(h, a, classes);                                                     \
+    }
+
 #define VDYN_DEFINE_LATTICE_ABI(S, T)                                                                    \
     extern "C" int vdyn_plan_lattice_##S##_dev(                                                          \
         VdynHandle *h, int32_t E, const T *px, const T *py, int32_t nwp, const T *ego, double goal_v,    \
@@ -819,6 +905,8 @@ VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
 VDYN_DEFINE_LATTICE_ABI(f32, float)
 VDYN_DEFINE_LATTICE_ABI(f64, double)
+VDYN_DEFINE_FLEET_ABI(f32, float)
+VDYN_DEFINE_FLEET_ABI(f64, double)
 VDYN_DEFINE_SELECT_ABI(f32, float)
 VDYN_DEFINE_SELECT_ABI(f64, double)
 VDYN_DEFINE_CTRL_ABI(f32, float)

@@ -28,10 +28,20 @@ struct RolloutArgs {
     T *state_dot = nullptr;      // nullable, last step's RK4-averaged derivative [10][n]
     T *outputs = nullptr;        // nullable, last step's RK4-averaged outputs   [18][n]
     int lanes_per_rollout = 1;   // 1: lane per rollout; 4: wheel-parallel (vdyn_quad.hpp)
+    const T *fleet_tab = nullptr;      // fleet rollouts: device table [V][len] of per-class constants
+    const int *vehicle_id = nullptr;   // fleet rollouts: device [n], class of every rollout
+    int V = 0;
 };
 
 template <typename T>
 hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st);
+
+template <typename T>
+hipError_t launch_rollout_fleet(const RolloutArgs<T> &a, bool all_small, hipStream_t st);
+template <typename T>
+void build_fleet_table(const VdynParams *classes, int V, const double *mu4, T *out, bool *all_small);
+template <typename T>
+int fleet_table_len(int V);
 
 template <typename T>
 hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, const T *ctrl12,

@@ -5,6 +5,8 @@
 // in SGPRs; lattice-shared control tables are staged through LDS; per-rollout
 // controls are read time-major so that a wave reads 64 consecutive values.
 #include "vdyn_internal.hpp"
+
+#include <cstring>
 #include "vdyn_device.hpp"
 #include "vdyn_controls.hpp"
 #include "vdyn_quad.hpp"
@@ -119,6 +121,81 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 for (int i = 0; i < 18; ++i) outputs_out[(int64_t)i * n + r] = o18.v[i];
             }
         }
+    }
+}
+
+// Heterogeneous fleet: every rollout carries a vehicle-class id; the classes' constants (masses,
+// geometry, static loads, Pacejka B / C per wheel: one DevParams<T> per class) are staged
+// through LDS once per workgroup and each lane copies its class's row into registers.  (With one
+// class -- every BASELINE configuration -- the constants are wave-uniform and the kernel above
+// keeps them in SGPRs instead, which is cheaper than any LDS read.)
+template <typename T> constexpr int dev_params_len() { return (int)(sizeof(DevParams<T>) / sizeof(T)); }
+
+template <typename T, int K, int LAYOUT, bool CS>
+__global__ void __launch_bounds__(kBlock)
+rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__ vehicle_id, int64_t n, int H,
+                     const T *__restrict__ state0, const T *__restrict__ ctrl, const int *__restrict__ path_id,
+                     int Pn, int chunk, T h, T *__restrict__ terminal, T *__restrict__ traj, int traj_stride)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int NP = dev_params_len<T>();
+    T *lds_fleet = reinterpret_cast<T *>(smem_raw);
+    T *tab = lds_fleet + (int64_t)V * NP;
+    for (int i = threadIdx.x; i < V * NP; i += kBlock) lds_fleet[i] = fleet[i];
+    __syncthreads();
+
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gid < n;
+    const int64_t r = active ? gid : n - 1;
+    DevParams<T> P;
+    {
+        const int vid = min(max(vehicle_id[r], 0), V - 1);
+        T *dst = reinterpret_cast<T *>(&P);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dst[i] = lds_fleet[vid * NP + i];
+    }
+    T s[10], ax, ay;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = state0[(int64_t)i * n + r];
+    ax = state0[10 * n + r];
+    ay = state0[11 * n + r];
+    int pid = 0;
+    if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);
+
+    for (int t0 = 0; t0 < H; t0 += chunk) {
+        const int tc_n = min(chunk, H - t0);
+        if (LAYOUT == 1) {
+            __syncthreads();
+            const int total = tc_n * K * Pn;
+            for (int idx = threadIdx.x; idx < total; idx += kBlock) {
+                const int p = idx % Pn;
+                const int kk = (idx / Pn) % K;
+                const int tc = idx / (Pn * K);
+                tab[idx] = ctrl[((int64_t)p * H + (t0 + tc)) * K + kk];
+            }
+            __syncthreads();
+        }
+        for (int tc = 0; tc < tc_n; ++tc) {
+            const int t = t0 + tc;
+            Ctrl<T, K> c;
+            if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
+            else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
+            else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
+            rk4_advance<T, K == 2, false, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, nullptr, nullptr);
+            if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) row[(int64_t)i * n] = s[i];
+                row[10 * n] = ax;
+                row[11 * n] = ay;
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) terminal[(int64_t)i * n + r] = s[i];
+        terminal[10 * n + r] = ax;
+        terminal[11 * n + r] = ay;
     }
 }
 
@@ -740,6 +817,57 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
 }
 
 template <typename T, int K, int LAYOUT, bool CS>
+static hipError_t launch_rollout_fleet_impl(const RolloutArgs<T> &a, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    const size_t fleet_bytes = (size_t)a.V * dev_params_len<T>() * sizeof(T);
+    int chunk = a.H > 0 ? a.H : 1;
+    size_t lds = fleet_bytes;
+    if (LAYOUT == 1) {
+        const size_t per_step = (size_t)a.P * K * sizeof(T);
+        chunk = (int)std::min<size_t>((size_t)chunk, std::max<size_t>(1, (kLdsBudget - 16 * 1024) / per_step));
+        lds += (size_t)chunk * per_step;
+    }
+    hipLaunchKernelGGL((rollout_fleet_kernel<T, K, LAYOUT, CS>), dim3(grid), dim3(kBlock), lds, st, a.fleet_tab, a.V,
+                       a.vehicle_id, a.n, a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                       a.traj_stride > 0 ? a.traj_stride : 1);
+    return hipGetLastError();
+}
+
+// Host side of the fleet table: one DevParams<T> per class, laid out as plain T words.
+template <typename T>
+void build_fleet_table(const VdynParams *classes, int V, const double *mu4, T *out, bool *all_small)
+{
+    *all_small = true;
+    for (int v = 0; v < V; ++v) {
+        const DevParams<T> d = make_dev_params<T>(classes[v], mu4);
+        std::memcpy(out + (size_t)v * dev_params_len<T>(), &d, sizeof(d));
+        *all_small = *all_small && shape_factors_small(classes[v]);
+    }
+}
+template <typename T> int fleet_table_len(int V) { return V * dev_params_len<T>(); }
+
+template <typename T>
+hipError_t launch_rollout_fleet(const RolloutArgs<T> &a, bool all_small, hipStream_t st)
+{
+    if (a.n <= 0) return hipSuccess;
+    int layout = a.layout;
+    if (layout == VDYN_CTRL_SHARED && (size_t)a.P * a.k * sizeof(T) > (size_t)(kLdsBudget - 16 * 1024)) layout = 2;
+#define VDYN_DISPATCH_F(KK, LL)                                                        \
+    if (a.k == KK && layout == LL)                                                     \
+        return all_small ? launch_rollout_fleet_impl<T, KK, LL, true>(a, st)           \
+                         : launch_rollout_fleet_impl<T, KK, LL, false>(a, st);
+    VDYN_DISPATCH_F(2, 0)
+    VDYN_DISPATCH_F(2, 1)
+    VDYN_DISPATCH_F(2, 2)
+    VDYN_DISPATCH_F(12, 0)
+    VDYN_DISPATCH_F(12, 1)
+    VDYN_DISPATCH_F(12, 2)
+#undef VDYN_DISPATCH_F
+    return hipErrorInvalidValue;
+}
+
+template <typename T, int K, int LAYOUT, bool CS>
 static hipError_t launch_rollout_quad_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
 {
     const DevParams<T> P = make_dev_params<T>(p, a.mu4);
@@ -939,6 +1067,9 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
                                               const ClosedLoopArgs<T> &, hipStream_t);               \
     template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t); \
     template hipError_t launch_select_best_path<T>(const SelectArgs<T> &, hipStream_t);             \
+    template hipError_t launch_rollout_fleet<T>(const RolloutArgs<T> &, bool, hipStream_t);          \
+    template void build_fleet_table<T>(const VdynParams *, int, const double *, T *, bool *);        \
+    template int fleet_table_len<T>(int);                                                            \
     template hipError_t launch_plan_lattice<T>(const LatticeArgs<T> &, hipStream_t);                 \
     template hipError_t launch_interpolate_waypoints<T>(int, int, int, const T *, const int *, double, int, T *, \
                                                         int *, hipStream_t);

@@ -336,6 +336,47 @@ class VehicleModel:
         del keep
         return (term, traj) if traj_stride > 0 else term
 
+    def rollout_fleet(self, states0, controls, classes, vehicle_id, dt=None, path_id=None, mu_max=None,
+                      traj_stride=0):
+        """``rollout`` for a heterogeneous fleet: ``classes`` is a sequence of VehicleParameters-like
+        objects (at most 256), ``vehicle_id [N]`` the class of every rollout.  The classes' constants
+        are staged through LDS; each lane keeps its class's set in registers."""
+        be = _Backend(states0)
+        s0 = be.inp(states0)
+        if s0.ndim != 2 or s0.shape[0] != 12:
+            raise ValueError("states0 must be [12][N]")
+        n = s0.shape[1]
+        ct = be.inp(controls)
+        if ct.ndim != 3:
+            raise ValueError("controls must be [H][k][N] or [P][H][k]")
+        if path_id is None:
+            H, k, nn = ct.shape
+            if nn != n:
+                raise ValueError("controls must be [H][k][N] with N matching states0")
+            layout, P, pid = _lib.VDYN_CTRL_PER_ROLLOUT, 0, None
+        else:
+            P, H, k = ct.shape
+            pid = be.inp(path_id, shape=(n,), int32=True)
+            layout = _lib.VDYN_CTRL_SHARED
+        if k not in (2, 12):
+            raise ValueError("k must be 2 or 12")
+        V = len(classes)
+        if not 1 <= V <= 256:
+            raise ValueError("1..256 vehicle classes")
+        ctab = (VdynParams * V)(*[params_to_c(c) for c in classes])
+        vid = be.inp(vehicle_id, shape=(n,), int32=True)
+        if not be.torch and n and (int(vid.min()) < 0 or int(vid.max()) >= V):
+            raise ValueError("vehicle_id out of range")
+        keep, mu4 = self._mu4(mu_max)
+        term = be.out(12, n)
+        traj = be.out(H // traj_stride, 12, n) if traj_stride > 0 else None
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_rollout_fleet_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(ct), int(k), layout, _vp(pid),
+            int(P), ctab, V, _vp(vid), float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj),
+            int(traj_stride), *be.stream_args())
+        del keep
+        return (term, traj) if traj_stride > 0 else term
+
     def mpc_argmin(self, ego, cand, goal, dt=None, w_delta=1e-3, return_costs=False, p=None):
         """BASELINE config 5: ``ego [12][E]``, shared candidates ``cand [H][2][C]``,
         ``goal [2][E]`` -> ``(best_cost [E], best_idx [E])`` (+ ``cost [E][C]``)."""

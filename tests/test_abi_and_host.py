@@ -29,7 +29,7 @@ def lib(pkg):
 
 def test_header_symbols_all_exported(lib):
     syms = declared_symbols()
-    assert len(syms) == 10 + 2 * 18, syms
+    assert len(syms) == 10 + 2 * 20, syms
     dll = ctypes.CDLL(lib.LIB_PATH)
     for s in syms:
         assert hasattr(dll, s), f"{s} declared in include/vdyn.h but not exported"

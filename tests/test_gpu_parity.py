@@ -784,3 +784,34 @@ def test_widened_entry_points_argument_errors_and_empty_batches(gpu_vm, pkg):
     paths[0, :, 1] = np.array([[-1.0], [0.2], [1.0]])
     f, b, s = vm.select_best_path(paths, np.zeros((0, 2)), np.array([[4.0], [0.0]]))
     assert f.all() and b[0] == 1 and abs(s[0] - 0.2) < 1e-12
+
+
+def test_heterogeneous_fleet_rollout(gpu_vm, pkg, oracle, workloads):
+    """rollout_fleet: 5 vehicle classes (masses, geometry, tire stiffness / shape all different, one
+    with a shape factor above 2 that forces the general sin path) mixed over 3000 rollouts, against
+    the oracle run class by class; a one-class fleet equals the plain rollout bit for bit."""
+    VP = pkg.VehicleParameters
+    classes = [VP(), VP(mf=1100.0, mr=950.0, L=3.1), VP(T=1.65, hg=0.62, Jw=1.4), VP(BFL=16.0, CFL=1.3),
+               VP(BFL=24.0, CFL=2.3)]
+    classes[2].BRL = classes[2].BRR = 0.8 * classes[2].BFL          # vehicle_model.py:237-242 experiment
+    n, H, dt = 3000, 80, 1e-3
+    rng = np.random.default_rng(21)
+    vid = rng.integers(0, len(classes), n).astype(np.int32)
+    s0, tab, pid = workloads.config3(n, H, np.float64)
+    rw = np.array([c.rw for c in classes])[vid]
+    s0[3:7] = s0[0] / rw * (1 + rng.uniform(-0.01, 0.01, (4, n)))
+    vm = gpu_vm(dt)
+    got = vm.rollout_fleet(s0, tab, classes, vid, path_id=pid)
+    want = np.empty_like(got)
+    for v, c in enumerate(classes):
+        m = vid == v
+        want[:, m] = oracle.rollout(oracle.params_from(c), s0[:, m], tab, dt, path_id=pid[m])
+    assert parity(got, want, F64_TOL) <= 1e-9
+    g32 = vm.rollout_fleet(s0.astype(np.float32), tab.astype(np.float32), classes, vid, path_id=pid)
+    assert parity(g32, want, F32_TOL) <= 3e-4
+    ctrl = workloads.expand_shared_controls(tab, pid)
+    assert np.array_equal(vm.rollout_fleet(s0, ctrl, classes, vid), got)            # per-rollout controls layout
+    one = vm.rollout_fleet(s0, tab, [classes[0]], np.zeros(n, np.int32), path_id=pid)
+    assert np.array_equal(one, gpu_vm(dt, params=classes[0]).rollout(s0, tab, path_id=pid))
+    with pytest.raises(ValueError):
+        vm.rollout_fleet(s0, tab, classes, vid + 3, path_id=pid)
