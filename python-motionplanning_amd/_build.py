@@ -16,8 +16,10 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # VDYN_LIB_PATH: load/build an alternative in-tree build (A/B experiments only)
 LIB_PATH = os.environ.get("VDYN_LIB_PATH") or os.path.join(PKG_DIR, "libvdyn_hip.so")
 SOURCES = ["vdyn_kernels.hip", "vdyn_capi.hip"]
-HEADERS = [os.path.join(CSRC, "vdyn_device.hpp"), os.path.join(CSRC, "vdyn_internal.hpp"),
-           os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("vdyn_device.hpp", "vdyn_internal.hpp", "vdyn_fastmath.hpp",
+                                           "vdyn_packed.hpp", "vdyn_controls.hpp", "vdyn_quad.hpp",
+                                           "vdyn_lattice.hpp")] + \
+          [os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-fast-math", "-Wall", "-Wno-unused-function",
                # packed fp32 VALU issues at half rate on gfx950, so SLP-packing scalar

@@ -8,6 +8,7 @@
 
 #include <cstring>
 #include "vdyn_device.hpp"
+#include "vdyn_packed.hpp"
 #include "vdyn_controls.hpp"
 #include "vdyn_quad.hpp"
 #include "vdyn_lattice.hpp"
@@ -73,6 +74,8 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
 
     T sd[10];
     Outputs18<T> o18;
+    StepEngine<T> eng;
+    if (!DIAG) eng.init(P);
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
@@ -94,7 +97,8 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
 
-            rk4_advance<T, K == 2, DIAG, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
+            if (DIAG) rk4_advance<T, K == 2, true, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
+            else eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
@@ -161,6 +165,8 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
     ay = state0[11 * n + r];
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);
+    StepEngine<T> eng;
+    eng.init(P);
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
@@ -181,7 +187,7 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
             if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
-            rk4_advance<T, K == 2, false, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, nullptr, nullptr);
+            eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
 #pragma unroll
@@ -350,6 +356,8 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
 
     T bc = inf;
     int bi = kNone;
+    StepEngine<T> eng;
+    eng.init(P);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         T s[10], ax = ax0, ay = ay0, dsum = T(0);
 #pragma unroll
@@ -357,7 +365,7 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         for (int t = 0; t < H; ++t) {
             Ctrl<T, 2> cc;
             cc.set(P, cand + ((int64_t)t * 2) * C + c, C);
-            rk4_advance<T, true, false, CS>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h, nullptr, nullptr);
+            eng.template advance<true, CS>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h);
             dsum += cc.delta[0] * cc.delta[0];
         }
         const T dx = s[8] - gx, dy = s[9] - gy;
@@ -472,6 +480,8 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : nullptr;
     w.bounds = WPLDS ? lds_bnd + (int64_t)pid * nbmax * 4 : nullptr;
     w.W = min(max(wcount[pid], 1), Wmax);
+    StepEngine<T> eng;
+    if (!DATALOG) eng.init(P);
 
     for (int t = 0; t < H; ++t) {
         if ((phase + t) % ctrl_every == 0) {   // wave-uniform test
@@ -482,7 +492,8 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
         T sd[10];
         Outputs18<T> o18;
-        rk4_advance<T, true, DATALOG, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, &o18);
+        if (DATALOG) rk4_advance<T, true, true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, &o18);
+        else eng.template advance<true, CS>(P, s, ax, ay, delta, tq, P.mu, h);
         if (DATALOG && active) {
             T *row = datalog + (int64_t)t * 45 * n + r;
             row[0] = (T)(phase + t) * h;                                          // drive.py:145

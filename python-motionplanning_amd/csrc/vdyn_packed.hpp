@@ -1,0 +1,373 @@
+// vdyn_packed.hpp -- the fp32 FAST step on packed (2 x fp32) VALU instructions.
+//
+// Why: at one wave per SIMD -- what 65536 rollouts give this chip -- throughput is bound by
+// how often ONE wave can issue, not by the ALUs: a lone wave issues one VALU instruction per
+// ~4.5 cycles whether it is v_fma_f32 or v_pk_fma_f32 (tools/ubench/issue_rate.hip: 5.4 vs 5.7
+// cycles at the 2.4 GHz nominal clock), so a packed instruction does two lanes' worth of work
+// in one issue slot.  (With 2+ waves per SIMD a packed op costs two scalar ops, i.e. nothing is
+// lost there either.)  The model pairs up naturally: (FL, FR) and (RL, RR) run the same tire
+// computation, and the ten states advance as five pairs.
+//
+// What cannot be packed stays scalar on the halves of a pair: v_rcp / v_rsq, compares and
+// selects, min / max, |x|.  Polynomial coefficients live in VGPR pairs for the whole kernel
+// (VOP3P takes no literal constants on gfx9); PkConsts::init pins them there.
+//
+// Semantics are those of vdyn_device.hpp (same formulas, same quirk handling); only the order
+// of the four-tire sums differs ((FL+RL)+(FR+RR) instead of ((FL+FR)+RL)+RR).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vdyn_device.hpp"
+
+namespace vdyn {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Coefficients and other constants as (c, c) pairs, made opaque to the optimiser so that they are
+// materialised once and stay in VGPRs instead of being rebuilt at every use.
+struct PkConsts {
+    f2 at[8];            // atan: c8 .. c1 (vdyn_fastmath.hpp, atan_rcp)
+    f2 sn[4];            // sin on [-pi/2, pi/2]: the four coefficients of sin_mid / sin_0_pi
+    f2 pi_hi, pi_lo, inv_pi, pio2;
+    f2 side;             // (-1, +1): left / right wheel (quirk Q8)
+    f2 sk[3], ck[3];     // sin / cos kernels on |r| <= pi/4 (sincos_kernel)
+
+    __device__ __forceinline__ void pin(f2 &v, float c)
+    {
+        v = splat(c);
+        asm volatile("" : "+v"(v));
+    }
+    __device__ __forceinline__ void init()
+    {
+        const float a[8] = {2.872858429e-03f, -1.616817340e-02f, 4.286647215e-02f, -7.520283014e-02f,
+                            1.064901948e-01f, -1.420586258e-01f, 1.999291778e-01f, -3.333308995e-01f};
+        const float s[4] = {2.607052693e-06f, -1.981028618e-04f, 8.333077654e-03f, -1.666665971e-01f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pin(at[i], a[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pin(sn[i], s[i]);
+        pin(pi_hi, 3.1415927410125732421875f);
+        pin(pi_lo, -8.74227800037248566e-08f);
+        pin(inv_pi, 0.318309886183790671538f);
+        pin(pio2, 1.57079637050628662109375f);
+        side = f2{-1.0f, 1.0f};
+        asm volatile("" : "+v"(side));
+        const float sks[3] = {-1.951163867e-04f, 8.332134224e-03f, -1.666665375e-01f};
+        const float cks[3] = {2.443367339e-05f, -1.388732577e-03f, 4.166664556e-02f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { pin(sk[i], sks[i]); pin(ck[i], cks[i]); }
+    }
+};
+
+// Vehicle constants as pairs (front axle pair F = (FL, FR), rear pair R = (RL, RR)).
+struct PkParams {
+    f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw, a_b;   // a_b = (a, a) for the front pair use, see below
+    f2 ab_F, ab_R;                                       // (+a, +a), (-b, -b): lever arms of the pairs
+    f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
+    __device__ __forceinline__ void init(const DevParams<float> &P)
+    {
+        BF = f2{P.B[0], P.B[1]}; BR = f2{P.B[2], P.B[3]};
+        invBF = f2{P.invB[0], P.invB[1]}; invBR = f2{P.invB[2], P.invB[3]};
+        CF = f2{P.C[0], P.C[1]}; CR = f2{P.C[2], P.C[3]};
+        rw = splat(P.rw); inv_Jw = splat(P.inv_Jw);
+        ab_F = splat(P.a); ab_R = splat(-P.b);
+        a_b = f2{P.a, P.b};
+        a_negb = f2{P.a, -P.b};
+        hT_side = f2{-P.half_T, P.half_T};
+        inv_m = splat(P.inv_m);
+    }
+};
+
+// The front pair (FL, FR) and the rear pair (RL, RR) are evaluated in lockstep, statement by
+// statement: a packed instruction may not be followed immediately by one that reads its result
+// (the compiler pads with s_nop, which costs a lone wave a whole issue slot), and the other
+// pair's independent instruction is exactly the filler that makes the padding unnecessary.
+#define VDYN_BOTH(q) _Pragma("unroll") for (int q = 0; q < 2; ++q)
+
+// sin(C atan(x)) for both pairs; inv_x = 1/x per half.
+template <bool CS>
+__device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], const f2 x[2], const f2 inv_x[2],
+                                              f2 out[2])
+{
+    // atan_rcp on all four halves: selects scalar, Horner chain packed
+    bool b0[2], b1[2];
+    f2 t[2], u[2], p[2], th[2], y[2], r[2], w[2], ps[2], kk[2];
+    VDYN_BOTH(q) { b0[q] = ::fabsf(x[q].x) > 1.0f; b1[q] = ::fabsf(x[q].y) > 1.0f; }
+    VDYN_BOTH(q) t[q] = f2{b0[q] ? inv_x[q].x : x[q].x, b1[q] ? inv_x[q].y : x[q].y};
+    VDYN_BOTH(q) u[q] = t[q] * t[q];
+    VDYN_BOTH(q) p[q] = K.at[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) VDYN_BOTH(q) p[q] = fma2(p[q], u[q], K.at[i]);
+    VDYN_BOTH(q) p[q] = p[q] * u[q];
+    VDYN_BOTH(q) p[q] = fma2(p[q], t[q], t[q]);
+    if (CS) {
+        // CS implies B >= 0, hence x = B s >= 0: atan(x) = pi/2 - atan(1/x) above 1, no sign to carry
+        f2 d[2];
+        VDYN_BOTH(q) d[q] = K.pio2 - p[q];
+        VDYN_BOTH(q) th[q] = f2{b0[q] ? d[q].x : p[q].x, b1[q] ? d[q].y : p[q].y};
+    } else {
+        const float pio2 = 1.57079637050628662109375f;
+        VDYN_BOTH(q) th[q] = f2{b0[q] ? (::copysignf(pio2, x[q].x) - p[q].x) : p[q].x,
+                               b1[q] ? (::copysignf(pio2, x[q].y) - p[q].y) : p[q].y};
+    }
+    VDYN_BOTH(q) y[q] = C[q] * th[q];
+    if (CS) {
+        // sin on [0, pi] by reflection about pi/2 (vdyn_fastmath.hpp, sin_0_pi)
+        f2 m[2];
+        VDYN_BOTH(q) m[q] = K.pi_hi - y[q];
+        VDYN_BOTH(q) m[q] = m[q] + K.pi_lo;
+        VDYN_BOTH(q) r[q] = f2{::fminf(y[q].x, m[q].x), ::fminf(y[q].y, m[q].y)};
+    } else {
+        VDYN_BOTH(q) kk[q] = y[q] * K.inv_pi;
+        VDYN_BOTH(q) kk[q] = f2{__builtin_rintf(kk[q].x), __builtin_rintf(kk[q].y)};
+        VDYN_BOTH(q) r[q] = fma2(-kk[q], K.pi_hi, y[q]);
+        VDYN_BOTH(q) r[q] = fma2(-kk[q], K.pi_lo, r[q]);
+    }
+    VDYN_BOTH(q) w[q] = r[q] * r[q];
+    VDYN_BOTH(q) ps[q] = fma2(K.sn[0], w[q], K.sn[1]);
+    VDYN_BOTH(q) ps[q] = fma2(ps[q], w[q], K.sn[2]);
+    VDYN_BOTH(q) ps[q] = fma2(ps[q], w[q], K.sn[3]);
+    VDYN_BOTH(q) w[q] = r[q] * w[q];
+    VDYN_BOTH(q) out[q] = fma2(w[q], ps[q], r[q]);
+    if (!CS) {
+        VDYN_BOTH(q) {
+            const unsigned f0 = ((unsigned)(int)kk[q].x) << 31, f1 = ((unsigned)(int)kk[q].y) << 31;
+            out[q] = f2{__uint_as_float(__float_as_uint(out[q].x) ^ f0), __uint_as_float(__float_as_uint(out[q].y) ^ f1)};
+        }
+    }
+}
+
+// All four tires (vehicle_model.py:274-373, as tire_force in vdyn_device.hpp): index 0 = front
+// pair (always steered), index 1 = rear pair (steered only with k = 12 controls).
+template <bool REAR_STEERED, bool CS>
+__device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], const f2 invB[2], const f2 C[2], f2 rw,
+                                              f2 vxc, const f2 vyc[2], const f2 w[2], const f2 cd[2], const f2 sd[2],
+                                              const f2 muFz[2], f2 fx[2], f2 fy[2], f2 fxt[2], f2 fyt[2])
+{
+    f2 vx[2], vy[2], rvx[2], sx[2], sy[2], s2[2], rs[2], s[2], xs[2], ix[2], g[2], tmp[2];
+    tmp[0] = vyc[0] * sd[0];
+    vx[0] = fma2(vxc, cd[0], tmp[0]);
+    tmp[0] = vxc * sd[0];
+    vy[0] = fma2(vyc[0], cd[0], -tmp[0]);
+    if (REAR_STEERED) {
+        tmp[1] = vyc[1] * sd[1];
+        vx[1] = fma2(vxc, cd[1], tmp[1]);
+        tmp[1] = vxc * sd[1];
+        vy[1] = fma2(vyc[1], cd[1], -tmp[1]);
+    } else {
+        vx[1] = vxc;
+        vy[1] = vyc[1];
+    }
+    VDYN_BOTH(q) rvx[q] = f2{fm::rcp(vx[q].x), fm::rcp(vx[q].y)};
+    VDYN_BOTH(q) sx[q] = fma2(rw, w[q], -vx[q]);
+    VDYN_BOTH(q) sx[q] = sx[q] * rvx[q];
+    VDYN_BOTH(q) sy[q] = f2{-vy[q].x * ::fabsf(rvx[q].x), -vy[q].y * ::fabsf(rvx[q].y)};          // quirk Q4
+    VDYN_BOTH(q) s2[q] = sy[q] * sy[q];
+    VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);
+    VDYN_BOTH(q) s2[q] = f2{::fmaxf(s2[q].x, 1e-30f), ::fmaxf(s2[q].y, 1e-30f)};                 // quirk Q5
+    VDYN_BOTH(q) rs[q] = f2{fm::rsq(s2[q].x), fm::rsq(s2[q].y)};
+    VDYN_BOTH(q) s[q] = s2[q] * rs[q];
+    VDYN_BOTH(q) xs[q] = B[q] * s[q];
+    VDYN_BOTH(q) ix[q] = rs[q] * invB[q];
+    sin_c_atan2x2<CS>(K, C, xs, ix, g);
+    VDYN_BOTH(q) g[q] = g[q] * rs[q];
+    VDYN_BOTH(q) g[q] = g[q] * muFz[q];
+    VDYN_BOTH(q) fxt[q] = sx[q] * g[q];
+    VDYN_BOTH(q) fyt[q] = sy[q] * g[q];
+    tmp[0] = fyt[0] * sd[0];
+    fx[0] = fma2(fxt[0], cd[0], -tmp[0]);
+    tmp[0] = fyt[0] * cd[0];
+    fy[0] = fma2(fxt[0], sd[0], tmp[0]);
+    if (REAR_STEERED) {
+        tmp[1] = fyt[1] * sd[1];
+        fx[1] = fma2(fxt[1], cd[1], -tmp[1]);
+        tmp[1] = fyt[1] * cd[1];
+        fy[1] = fma2(fxt[1], sd[1], tmp[1]);
+    } else {
+        fx[1] = fxt[1];
+        fy[1] = fyt[1];
+    }
+}
+
+// The ten states as five pairs.
+struct State5 {
+    f2 uv;    // U, V
+    f2 wy;    // wz, yaw
+    f2 wf;    // wFL, wFR
+    f2 wr;    // wRL, wRR
+    f2 xy;    // x, y
+};
+
+struct StepInv2 {
+    f2 cdF, sdF, cdR, sdR;   // cos / sin of the steering angles per pair
+    f2 muFzF, muFzR;         // mu_max * Fz
+    f2 tqF, tqR;
+};
+
+// vehicle_model.py:220-425 on pairs.  (sy, cy) = sin, cos of the stage yaw.
+template <bool K2, bool CS>
+__device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
+                                              const StepInv2 &c, const State5 &s, float sy, float cy, State5 &k,
+                                              float &axc, float &ayc)
+{
+    const float U = s.uv.x, V = s.uv.y, wz = s.wy.x;
+    const f2 U2 = f2{U, U}, V2 = f2{V, V}, wz2 = f2{wz, wz};
+    const f2 vxc = fma2(Q.hT_side, wz2, U2);                  // :261-271 (left, right), both axles (quirk Q8)
+    const f2 vyb = fma2(Q.a_negb, wz2, V2);                   // (V + a wz, V - b wz): front, rear
+    const f2 Bq[2] = {Q.BF, Q.BR}, iBq[2] = {Q.invBF, Q.invBR}, Cq[2] = {Q.CF, Q.CR};
+    const f2 vyq[2] = {f2{vyb.x, vyb.x}, f2{vyb.y, vyb.y}}, wq[2] = {s.wf, s.wr};
+    const f2 cdq[2] = {c.cdF, c.cdR}, sdq[2] = {c.sdF, c.sdR}, mfq[2] = {c.muFzF, c.muFzR};
+    f2 fxq[2], fyq[2], fxtq[2], fytq[2];
+    tire_force2x2<!K2, CS>(K, Bq, iBq, Cq, Q.rw, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq);
+    const f2 fxF = fxq[0], fyF = fyq[0], fxtF = fxtq[0], fxR = fxq[1], fyR = fyq[1];
+    // :376-378
+    const f2 sfx = fxF + fxR, sfy = fyF + fyR;                 // (left sums, right sums)
+    const f2 sums = f2{sfx.x + sfx.y, sfy.x + sfy.y};          // (sum Fx, sum Fy)
+    const f2 cr0 = f2{V, U} * wz2;
+    const f2 cross = f2{cr0.x, -cr0.y};                        // (V wz, -U wz)
+    k.uv = fma2(Q.inv_m, sums, cross);                         // (U_dot, V_dot)
+    const f2 accs = k.uv - cross;                              // :413-414 (axc, ayc)
+    axc = accs.x;
+    ayc = accs.y;
+    const f2 my = fma2(fyF, Q.ab_F, fyR * Q.ab_R);             // a fy_front - b fy_rear, per side
+    const float wzdot = P.inv_Izz * ((my.x + my.y) + P.half_T * (sfx.y - sfx.x));
+    k.wy = f2{wzdot, wz};
+    k.wf = fma2(-Q.rw, fxtF, c.tqF) * Q.inv_Jw;                // quirk Q2: tire-frame force in front,
+    k.wr = fma2(-Q.rw, fxR, c.tqR) * Q.inv_Jw;                 //           chassis-frame force at the rear
+    const f2 vr = V2 * f2{sy, cy};
+    k.xy = fma2(U2, f2{cy, sy}, f2{-vr.x, vr.y});              // :384-385
+}
+
+// FAST RK4 step (vehicle_model.py:427-445) on pairs; `ok` as in rk4_step.
+template <bool K2, bool CS>
+__device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
+                                          const State5 &s, float ax, float ay, const float delta[4],
+                                          const float tq[4], const float mu[4], float h, State5 &sn, float &axn,
+                                          float &ayn)
+{
+    using M = Math<float, false>;
+    bool ok = true;
+    StepInv2 c;
+    {
+        float s0, c0;
+        M::sincos(delta[0], &s0, &c0, ok);
+        if (K2) {
+            c.sdF = splat(s0); c.cdF = splat(c0);
+            c.sdR = splat(0.0f); c.cdR = splat(1.0f);
+        } else {
+            float s1, c1, s2, c2, s3, c3;
+            M::sincos(delta[1], &s1, &c1, ok);
+            M::sincos(delta[2], &s2, &c2, ok);
+            M::sincos(delta[3], &s3, &c3, ok);
+            c.sdF = f2{s0, s1}; c.cdF = f2{c0, c1};
+            c.sdR = f2{s2, s3}; c.cdR = f2{c2, c3};
+        }
+        // :255-258 (quirk Q3), then mu_max * Fz (quirk Q1)
+        const float FzFL = P.Fz0F - P.DfzxL * ax - P.DfzyF * ay, FzFR = P.Fz0F - P.DfzxR * ax + P.DfzyF * ay;
+        const float FzRL = P.Fz0R + P.DfzxL * ax - P.DfzyR * ay, FzRR = P.Fz0R + P.DfzxR * ax + P.DfzyR * ay;
+        c.muFzF = f2{mu[0] * FzFL, mu[1] * FzFR};
+        c.muFzR = f2{mu[2] * FzRL, mu[3] * FzRR};
+        c.tqF = f2{tq[0], tq[1]};
+        c.tqR = f2{tq[2], tq[3]};
+    }
+    const float hh = 0.5f * h;
+    const f2 hh2 = splat(hh), h2 = splat(h), two = splat(2.0f);
+    float sy0, cy0, sy, cy, a1, a2, asx, asy;
+    M::sincos(s.wy.y, &sy0, &cy0, ok);
+    State5 k, acc, st;
+
+#define VDYN_S5_EACH(OP) OP(uv) OP(wy) OP(wf) OP(wr) OP(xy)
+    planar_deriv2<K2, CS>(P, Q, K, c, s, sy0, cy0, k, a1, a2);                    // K1
+    asx = a1; asy = a2;
+#define VDYN_S5_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
+    VDYN_S5_EACH(VDYN_S5_1)
+    M::stage_sincos(sy0, cy0, st.wy.y, hh * k.wy.y, &sy, &cy, ok);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sy, cy, k, a1, a2);                     // K2
+    asx = ::fmaf(2.0f, a1, asx); asy = ::fmaf(2.0f, a2, asy);
+#define VDYN_S5_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
+    VDYN_S5_EACH(VDYN_S5_2)
+    M::stage_sincos(sy0, cy0, st.wy.y, hh * k.wy.y, &sy, &cy, ok);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sy, cy, k, a1, a2);                     // K3
+    asx = ::fmaf(2.0f, a1, asx); asy = ::fmaf(2.0f, a2, asy);
+#define VDYN_S5_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
+    VDYN_S5_EACH(VDYN_S5_3)
+    M::stage_sincos(sy0, cy0, st.wy.y, h * k.wy.y, &sy, &cy, ok);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sy, cy, k, a1, a2);                     // K4
+    asx += a1; asy += a2;
+    const float sixth = 1.0f / 6.0f;
+    const f2 h6 = splat(h * sixth);
+#define VDYN_S5_4(f) sn.f = fma2(h6, acc.f + k.f, s.f);
+    VDYN_S5_EACH(VDYN_S5_4)
+#undef VDYN_S5_1
+#undef VDYN_S5_2
+#undef VDYN_S5_3
+#undef VDYN_S5_4
+#undef VDYN_S5_EACH
+    axn = asx * sixth;
+    ayn = asy * sixth;
+    return ok;
+}
+
+}  // namespace vdyn
+
+namespace vdyn {
+
+// What a kernel's time loop calls: per-kernel constants + one step.  fp32 takes the packed
+// FAST step (SAFE scalar redo for lanes that left its validated range, exactly as rk4_advance);
+// fp64 has no packed VALU form and goes through rk4_advance.
+template <typename T>
+struct StepEngine {
+    __device__ __forceinline__ void init(const DevParams<T> &) {}
+    template <bool K2, bool CS>
+    __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
+                                            const T tq[4], const T mu[4], T h) const
+    {
+        rk4_advance<T, K2, false, CS>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr);
+    }
+};
+
+template <>
+struct StepEngine<float> {
+    PkConsts K;
+    PkParams Q;
+    __device__ __forceinline__ void init(const DevParams<float> &P)
+    {
+        K.init();
+        Q.init(P);
+    }
+    template <bool K2, bool CS>
+    __device__ __forceinline__ void advance(const DevParams<float> &P, float s[10], float &ax, float &ay,
+                                            const float delta[4], const float tq[4], const float mu[4],
+                                            float h) const
+    {
+        State5 S, Sn;
+        S.uv = f2{s[0], s[1]};
+        S.wy = f2{s[2], s[7]};
+        S.wf = f2{s[3], s[4]};
+        S.wr = f2{s[5], s[6]};
+        S.xy = f2{s[8], s[9]};
+        float axn, ayn;
+        const bool ok = rk4_step2<K2, CS>(P, Q, K, S, ax, ay, delta, tq, mu, h, Sn, axn, ayn);
+        if (__builtin_expect(__any(!ok) != 0, 0)) {
+            if (!ok) {
+                float sn[10];
+                rk4_step<float, K2, false, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
+                Sn.uv = f2{sn[0], sn[1]};
+                Sn.wy = f2{sn[2], sn[7]};
+                Sn.wf = f2{sn[3], sn[4]};
+                Sn.wr = f2{sn[5], sn[6]};
+                Sn.xy = f2{sn[8], sn[9]};
+            }
+        }
+        s[0] = Sn.uv.x; s[1] = Sn.uv.y; s[2] = Sn.wy.x; s[7] = Sn.wy.y;
+        s[3] = Sn.wf.x; s[4] = Sn.wf.y; s[5] = Sn.wr.x; s[6] = Sn.wr.y;
+        s[8] = Sn.xy.x; s[9] = Sn.xy.y;
+        ax = axn;
+        ay = ayn;
+    }
+};
+
+}  // namespace vdyn
