@@ -74,9 +74,12 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(W):
+def cpu_baseline(W, gpu_terminal=None):
     """The oracle (oracle/, the checker -- never the product) timed on this host:
-    kind 'port'.  Bounded sample of the bench workload, sized for ~10-30 core-seconds."""
+    kind 'port'.  Bounded sample of the bench workload, sized for ~10-30 core-seconds.
+    ``gpu_terminal`` ([12][N] fp32, the bench kernel's own output): its error against the fp64
+    oracle result of the same workload is reported as BASELINE.json's second metric
+    ("fp32 max-abs state error")."""
     from oracle import oracle as O
     O.build()
     p = O.default_params()
@@ -87,14 +90,24 @@ def cpu_baseline(W):
     reps, t_all = 0, 0.0
     t0 = time.perf_counter()
     while t_all < 1.0 or reps < 2:      # whole 65536 x 200 workload, all cores, >= 1 s of wall
-        O.rollout(p, s0, tab, DT, path_id=pid, nthreads=threads)
+        ref = O.rollout(p, s0, tab, DT, path_id=pid, nthreads=threads)
         reps += 1
         t_all = time.perf_counter() - t0
     n1 = 8192                           # one core: 1/8 of the workload
     t0 = time.perf_counter()
     O.rollout(p, s0[:, :n1], tab, DT, path_id=pid[:n1], nthreads=1)
     t_one = time.perf_counter() - t0
+    err = None
+    if gpu_terminal is not None:
+        ref = np.asarray(ref[0] if isinstance(ref, tuple) else ref)
+        d = np.abs(gpu_terminal.astype(np.float64) - ref)
+        scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)   # per state row
+        names = "U V wz wFL wFR wRL wRR yaw x y ax ay".split()
+        err = {"max_abs": float(d.max()), "max_abs_row": names[int(d.max(axis=1).argmax())],
+               "max_rel_to_row_scale": float((d / scale).max()), "tolerance_rel": 1e-3,
+               "against": "fp64 C oracle, all 65536 rollouts x 200 steps, terminal [12][N]"}
     return {
+        "fp32_state_error": err,
         "value": reps * N_PER_GPU * HORIZON / t_all, "unit": "vehicle-steps/s", "cores": threads,
         "kind": "port",
         "sample": f"fp64 C oracle (gcc -O2 -ffp-contract=off, OpenMP): {reps} x the full bench workload "
@@ -230,7 +243,10 @@ def main():
         if world == 1 and not args.no_extra and not args.strong:
             out["extra"] = extra_configs(vm, W, torch, dev, s0, tab, pid)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(W)
+            cb = cpu_baseline(W, term.cpu().numpy() if not args.strong else None)
+            err = cb.pop("fp32_state_error")
+            if err is not None:
+                out["fp32_state_error"] = err
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["value"] / cb["value"]
         print(json.dumps(out))
