@@ -26,14 +26,40 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Packed multiplies with a per-half sign, which VOP3P encodes for free (neg_lo / neg_hi) but the
+// compiler only forms for whole-vector negation.  Half swizzles (op_sel) it does form by itself.
+// Operands must not come straight from v_rcp / v_rsq: the wait state a transcendental result
+// needs is the compiler's to insert, and it does not look inside inline asm.
+__device__ __forceinline__ f2 pk_cross(f2 a, f2 b)        // (a.y b.x, -a.x b.x)
+{
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 pk_above_one(f2 x, f2 big)  // per half: 1.0f if x > 1 else 0.0f   (big = 2^100)
+{
+    // (x - 1) 2^100 clamped to [0, 1]: the smallest x above 1 already gives 2^77, so the result is
+    // exactly 0 or 1 for every float (NaN -> 0)
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp" : "=v"(r) : "v"(x), "v"(big));
+    return r;
+}
+__device__ __forceinline__ f2 pk_hi_conj(f2 a, f2 b)      // (-a.y b.x, a.y b.y)
+{
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Coefficients and other constants as (c, c) pairs, made opaque to the optimiser so that they are
 // materialised once and stay in VGPRs instead of being rebuilt at every use.
 struct PkConsts {
     f2 at[8];            // atan: c8 .. c1 (vdyn_fastmath.hpp, atan_rcp)
     f2 sn[4];            // sin on [-pi/2, pi/2]: the four coefficients of sin_mid / sin_0_pi
     f2 pi_hi, pi_lo, inv_pi, pio2;
+    f2 big, neg2, tiny;  // 2^100 (indicator scale), -2, 1e-30 (floor of s^2, quirk Q5)
     f2 side;             // (-1, +1): left / right wheel (quirk Q8)
-    f2 sk[3], ck[3];     // sin / cos kernels on |r| <= pi/4 (sincos_kernel)
+    f2 sck[3];           // (sin, cos) kernel coefficients on |r| <= pi/4 (sincos_kernel), one pair per degree
 
     __device__ __forceinline__ void pin(f2 &v, float c)
     {
@@ -53,12 +79,18 @@ struct PkConsts {
         pin(pi_lo, -8.74227800037248566e-08f);
         pin(inv_pi, 0.318309886183790671538f);
         pin(pio2, 1.57079637050628662109375f);
+        pin(big, 0x1p100f);
+        pin(neg2, -2.0f);
+        pin(tiny, 1e-30f);
         side = f2{-1.0f, 1.0f};
         asm volatile("" : "+v"(side));
         const float sks[3] = {-1.951163867e-04f, 8.332134224e-03f, -1.666665375e-01f};
         const float cks[3] = {2.443367339e-05f, -1.388732577e-03f, 4.166664556e-02f};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { pin(sk[i], sks[i]); pin(ck[i], cks[i]); }
+        for (int i = 0; i < 3; ++i) {
+            sck[i] = f2{sks[i], cks[i]};
+            asm volatile("" : "+v"(sck[i]));
+        }
     }
 };
 
@@ -67,6 +99,7 @@ struct PkParams {
     f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw, a_b;   // a_b = (a, a) for the front pair use, see below
     f2 ab_F, ab_R;                                       // (+a, +a), (-b, -b): lever arms of the pairs
     f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
+    f2 Fz0F, Fz0R, dfxF, dfyF, dfxR, dfyR;               // static loads and load-transfer coefficients per pair (:255-258)
     __device__ __forceinline__ void init(const DevParams<float> &P)
     {
         BF = f2{P.B[0], P.B[1]}; BR = f2{P.B[2], P.B[3]};
@@ -78,6 +111,9 @@ struct PkParams {
         a_negb = f2{P.a, -P.b};
         hT_side = f2{-P.half_T, P.half_T};
         inv_m = splat(P.inv_m);
+        Fz0F = splat(P.Fz0F); Fz0R = splat(P.Fz0R);
+        dfxF = f2{-P.DfzxL, -P.DfzxR}; dfyF = f2{-P.DfzyF, P.DfzyF};
+        dfxR = f2{P.DfzxL, P.DfzxR}; dfyR = f2{-P.DfzyR, P.DfzyR};
     }
 };
 
@@ -94,9 +130,16 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
 {
     // atan_rcp on all four halves: selects scalar, Horner chain packed
     bool b0[2], b1[2];
-    f2 t[2], u[2], p[2], th[2], y[2], r[2], w[2], ps[2], kk[2];
-    VDYN_BOTH(q) { b0[q] = ::fabsf(x[q].x) > 1.0f; b1[q] = ::fabsf(x[q].y) > 1.0f; }
-    VDYN_BOTH(q) t[q] = f2{b0[q] ? inv_x[q].x : x[q].x, b1[q] ? inv_x[q].y : x[q].y};
+    f2 t[2], u[2], p[2], th[2], y[2], r[2], w[2], ps[2], kk[2], ind[2];
+    if (CS) {
+        // CS implies B >= 0, hence x = B s >= 0: the reduced argument is min(x, 1/x) and
+        // atan(x) = p + [x > 1] (pi/2 - 2 p), no compare, no select, no sign to carry
+        VDYN_BOTH(q) t[q] = f2{::fminf(x[q].x, inv_x[q].x), ::fminf(x[q].y, inv_x[q].y)};
+        VDYN_BOTH(q) ind[q] = pk_above_one(x[q], K.big);
+    } else {
+        VDYN_BOTH(q) { b0[q] = ::fabsf(x[q].x) > 1.0f; b1[q] = ::fabsf(x[q].y) > 1.0f; }
+        VDYN_BOTH(q) t[q] = f2{b0[q] ? inv_x[q].x : x[q].x, b1[q] ? inv_x[q].y : x[q].y};
+    }
     VDYN_BOTH(q) u[q] = t[q] * t[q];
     VDYN_BOTH(q) p[q] = K.at[0];
 #pragma unroll
@@ -104,10 +147,9 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
     VDYN_BOTH(q) p[q] = p[q] * u[q];
     VDYN_BOTH(q) p[q] = fma2(p[q], t[q], t[q]);
     if (CS) {
-        // CS implies B >= 0, hence x = B s >= 0: atan(x) = pi/2 - atan(1/x) above 1, no sign to carry
         f2 d[2];
-        VDYN_BOTH(q) d[q] = K.pio2 - p[q];
-        VDYN_BOTH(q) th[q] = f2{b0[q] ? d[q].x : p[q].x, b1[q] ? d[q].y : p[q].y};
+        VDYN_BOTH(q) d[q] = fma2(K.neg2, p[q], K.pio2);
+        VDYN_BOTH(q) th[q] = fma2(ind[q], d[q], p[q]);
     } else {
         const float pio2 = 1.57079637050628662109375f;
         VDYN_BOTH(q) th[q] = f2{b0[q] ? (::copysignf(pio2, x[q].x) - p[q].x) : p[q].x,
@@ -165,9 +207,11 @@ __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], 
     VDYN_BOTH(q) sx[q] = fma2(rw, w[q], -vx[q]);
     VDYN_BOTH(q) sx[q] = sx[q] * rvx[q];
     VDYN_BOTH(q) sy[q] = f2{-vy[q].x * ::fabsf(rvx[q].x), -vy[q].y * ::fabsf(rvx[q].y)};          // quirk Q4
-    VDYN_BOTH(q) s2[q] = sy[q] * sy[q];
+    // quirk Q5: s == 0 takes the fallback branch in the reference, whose value is what the regular
+    // formula yields for s -> 0; s^2 + 1e-30 keeps rsq finite there and is s^2 to the last bit
+    // wherever s^2 >= 1e-22 (below that the force is linear in slip and does not see s at all)
+    VDYN_BOTH(q) s2[q] = fma2(sy[q], sy[q], K.tiny);
     VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);
-    VDYN_BOTH(q) s2[q] = f2{::fmaxf(s2[q].x, 1e-30f), ::fmaxf(s2[q].y, 1e-30f)};                 // quirk Q5
     VDYN_BOTH(q) rs[q] = f2{fm::rsq(s2[q].x), fm::rsq(s2[q].y)};
     VDYN_BOTH(q) s[q] = s2[q] * rs[q];
     VDYN_BOTH(q) xs[q] = B[q] * s[q];
@@ -193,6 +237,50 @@ __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], 
 }
 
 // The ten states as five pairs.
+// (sin r, cos r) for |r| <= pi/4: vdyn_fastmath.hpp's sincos_kernel with both Horner chains in
+// one packed chain.
+__device__ __forceinline__ f2 sincos_kernel2(const PkConsts &K, float r)
+{
+    const float u = r * r;
+    const f2 u2 = f2{u, u};
+    f2 p = fma2(K.sck[0], u2, K.sck[1]);
+    p = fma2(p, u2, K.sck[2]);
+    const f2 a = f2{r, u} * u2;                                 // (r u, u u)
+    return fma2(a, p, f2{r, ::fmaf(-0.5f, u, 1.0f)});
+}
+
+// (sin x, cos x) for |x| <= fm::kSincosMidLimit (yaw is never wrapped, quirk Q7): sincos_mid.
+__device__ __forceinline__ f2 sincos_mid2(const PkConsts &K, float x, bool &ok)
+{
+    const float k = __builtin_rintf(x * 0.636619772367581343076f);
+    float r = ::fmaf(-k, 1.57079637050628662109375f, x);
+    r = ::fmaf(-k, -4.37113900018624283e-08f, r);
+    r = ::fmaf(-k, -1.7151245100059e-15f, r);
+    const f2 sc = sincos_kernel2(K, r);
+    const int q = (int)k;
+    const bool swap = (q & 1) != 0;
+    const float s0 = swap ? sc.y : sc.x, c0 = swap ? sc.x : sc.y;
+    const unsigned fs = ((unsigned)(q & 2)) << 30, fc = ((unsigned)((q + 1) & 2)) << 30;
+    ok = ok && (::fabsf(x) <= fm::kSincosMidLimit);
+    return f2{__uint_as_float(__float_as_uint(s0) ^ fs), __uint_as_float(__float_as_uint(c0) ^ fc)};
+}
+
+// (sin, cos) of a steering angle: no reduction inside |delta| <= pi/4 (every physical steering
+// range; max_steer is 30 deg in drive.py:51); beyond it the lane takes the SAFE step.
+__device__ __forceinline__ f2 sincos_steer2(const PkConsts &K, float d, bool &ok)
+{
+    ok = ok && (::fabsf(d) <= fm::kSincosKernelLimit);
+    return sincos_kernel2(K, d);
+}
+
+// (sin, cos) of (yaw0 + d) from sc0 = (sin, cos) of yaw0: rotation by the small increment d.
+__device__ __forceinline__ f2 stage_sincos2(const PkConsts &K, f2 sc0, float d, bool &ok)
+{
+    const f2 dd = sincos_kernel2(K, d);                         // (sin d, cos d)
+    ok = ok && (::fabsf(d) <= fm::kSincosKernelLimit);
+    return fma2(sc0, f2{dd.y, dd.y}, pk_cross(sc0, dd));        // (s0 cd + c0 sd, c0 cd - s0 sd)
+}
+
 struct State5 {
     f2 uv;    // U, V
     f2 wy;    // wz, yaw
@@ -207,11 +295,11 @@ struct StepInv2 {
     f2 tqF, tqR;
 };
 
-// vehicle_model.py:220-425 on pairs.  (sy, cy) = sin, cos of the stage yaw.
+// vehicle_model.py:220-425 on pairs.  sc = (sin, cos) of the stage yaw.
 template <bool K2, bool CS>
 __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
-                                              const StepInv2 &c, const State5 &s, float sy, float cy, State5 &k,
-                                              float &axc, float &ayc)
+                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, float &axc,
+                                              float &ayc)
 {
     const float U = s.uv.x, V = s.uv.y, wz = s.wy.x;
     const f2 U2 = f2{U, U}, V2 = f2{V, V}, wz2 = f2{wz, wz};
@@ -225,9 +313,10 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     const f2 fxF = fxq[0], fyF = fyq[0], fxtF = fxtq[0], fxR = fxq[1], fyR = fyq[1];
     // :376-378
     const f2 sfx = fxF + fxR, sfy = fyF + fyR;                 // (left sums, right sums)
-    const f2 sums = f2{sfx.x + sfx.y, sfy.x + sfy.y};          // (sum Fx, sum Fy)
-    const f2 cr0 = f2{V, U} * wz2;
-    const f2 cross = f2{cr0.x, -cr0.y};                        // (V wz, -U wz)
+    float sumx = sfx.x + sfx.y, sumy = sfy.x + sfy.y;
+    asm("" : "+v"(sumx));                                      // keep the two adds scalar: packing them costs 3 v_mov
+    const f2 sums = f2{sumx, sumy};                            // (sum Fx, sum Fy)
+    const f2 cross = pk_cross(s.uv, s.wy);                     // (V wz, -U wz)
     k.uv = fma2(Q.inv_m, sums, cross);                         // (U_dot, V_dot)
     const f2 accs = k.uv - cross;                              // :413-414 (axc, ayc)
     axc = accs.x;
@@ -237,8 +326,7 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     k.wy = f2{wzdot, wz};
     k.wf = fma2(-Q.rw, fxtF, c.tqF) * Q.inv_Jw;                // quirk Q2: tire-frame force in front,
     k.wr = fma2(-Q.rw, fxR, c.tqR) * Q.inv_Jw;                 //           chassis-frame force at the rear
-    const f2 vr = V2 * f2{sy, cy};
-    k.xy = fma2(U2, f2{cy, sy}, f2{-vr.x, vr.y});              // :384-385
+    k.xy = fma2(U2, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));     // :384-385 (U cy - V sy, U sy + V cy)
 }
 
 // FAST RK4 step (vehicle_model.py:427-445) on pairs; `ok` as in rk4_step.
@@ -248,54 +336,52 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
                                           const float tq[4], const float mu[4], float h, State5 &sn, float &axn,
                                           float &ayn)
 {
-    using M = Math<float, false>;
     bool ok = true;
     StepInv2 c;
     {
-        float s0, c0;
-        M::sincos(delta[0], &s0, &c0, ok);
+        const f2 d0 = sincos_steer2(K, delta[0], ok);
         if (K2) {
-            c.sdF = splat(s0); c.cdF = splat(c0);
+            c.sdF = f2{d0.x, d0.x}; c.cdF = f2{d0.y, d0.y};
             c.sdR = splat(0.0f); c.cdR = splat(1.0f);
         } else {
-            float s1, c1, s2, c2, s3, c3;
-            M::sincos(delta[1], &s1, &c1, ok);
-            M::sincos(delta[2], &s2, &c2, ok);
-            M::sincos(delta[3], &s3, &c3, ok);
-            c.sdF = f2{s0, s1}; c.cdF = f2{c0, c1};
-            c.sdR = f2{s2, s3}; c.cdR = f2{c2, c3};
+            const f2 d1 = sincos_steer2(K, delta[1], ok), d2 = sincos_steer2(K, delta[2], ok),
+                     d3 = sincos_steer2(K, delta[3], ok);
+            c.sdF = f2{d0.x, d1.x}; c.cdF = f2{d0.y, d1.y};
+            c.sdR = f2{d2.x, d3.x}; c.cdR = f2{d2.y, d3.y};
         }
         // :255-258 (quirk Q3), then mu_max * Fz (quirk Q1)
-        const float FzFL = P.Fz0F - P.DfzxL * ax - P.DfzyF * ay, FzFR = P.Fz0F - P.DfzxR * ax + P.DfzyF * ay;
-        const float FzRL = P.Fz0R + P.DfzxL * ax - P.DfzyR * ay, FzRR = P.Fz0R + P.DfzxR * ax + P.DfzyR * ay;
-        c.muFzF = f2{mu[0] * FzFL, mu[1] * FzFR};
-        c.muFzR = f2{mu[2] * FzRL, mu[3] * FzRR};
+        const f2 ax2 = f2{ax, ax}, ay2 = f2{ay, ay};
+        const f2 FzF = fma2(Q.dfyF, ay2, fma2(Q.dfxF, ax2, Q.Fz0F));
+        const f2 FzR = fma2(Q.dfyR, ay2, fma2(Q.dfxR, ax2, Q.Fz0R));
+        c.muFzF = f2{mu[0], mu[1]} * FzF;
+        c.muFzR = f2{mu[2], mu[3]} * FzR;
         c.tqF = f2{tq[0], tq[1]};
         c.tqR = f2{tq[2], tq[3]};
     }
     const float hh = 0.5f * h;
     const f2 hh2 = splat(hh), h2 = splat(h), two = splat(2.0f);
-    float sy0, cy0, sy, cy, a1, a2, asx, asy;
-    M::sincos(s.wy.y, &sy0, &cy0, ok);
+    float a1, a2, asx, asy;
+    const f2 sc0 = sincos_mid2(K, s.wy.y, ok);
+    f2 sc;
     State5 k, acc, st;
 
 #define VDYN_S5_EACH(OP) OP(uv) OP(wy) OP(wf) OP(wr) OP(xy)
-    planar_deriv2<K2, CS>(P, Q, K, c, s, sy0, cy0, k, a1, a2);                    // K1
+    planar_deriv2<K2, CS>(P, Q, K, c, s, sc0, k, a1, a2);                    // K1
     asx = a1; asy = a2;
 #define VDYN_S5_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_1)
-    M::stage_sincos(sy0, cy0, st.wy.y, hh * k.wy.y, &sy, &cy, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sy, cy, k, a1, a2);                     // K2
+    sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a1, a2);                     // K2
     asx = ::fmaf(2.0f, a1, asx); asy = ::fmaf(2.0f, a2, asy);
 #define VDYN_S5_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_2)
-    M::stage_sincos(sy0, cy0, st.wy.y, hh * k.wy.y, &sy, &cy, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sy, cy, k, a1, a2);                     // K3
+    sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a1, a2);                     // K3
     asx = ::fmaf(2.0f, a1, asx); asy = ::fmaf(2.0f, a2, asy);
 #define VDYN_S5_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_3)
-    M::stage_sincos(sy0, cy0, st.wy.y, h * k.wy.y, &sy, &cy, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sy, cy, k, a1, a2);                     // K4
+    sc = stage_sincos2(K, sc0, h * k.wy.y, ok);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a1, a2);                     // K4
     asx += a1; asy += a2;
     const float sixth = 1.0f / 6.0f;
     const f2 h6 = splat(h * sixth);
