@@ -99,6 +99,7 @@ struct PkParams {
     f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw, a_b;   // a_b = (a, a) for the front pair use, see below
     f2 ab_F, ab_R;                                       // (+a, +a), (-b, -b): lever arms of the pairs
     f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
+    f2 neg_rw_Jw;                                        // -rw / Jw
     f2 Fz0F, Fz0R, dfxF, dfyF, dfxR, dfyR;               // static loads and load-transfer coefficients per pair (:255-258)
     __device__ __forceinline__ void init(const DevParams<float> &P)
     {
@@ -111,6 +112,7 @@ struct PkParams {
         a_negb = f2{P.a, -P.b};
         hT_side = f2{-P.half_T, P.half_T};
         inv_m = splat(P.inv_m);
+        neg_rw_Jw = splat(-P.rw * P.inv_Jw);
         Fz0F = splat(P.Fz0F); Fz0R = splat(P.Fz0R);
         dfxF = f2{-P.DfzxL, -P.DfzxR}; dfyF = f2{-P.DfzyF, P.DfzyF};
         dfxR = f2{P.DfzxL, P.DfzxR}; dfyR = f2{-P.DfzyR, P.DfzyR};
@@ -292,14 +294,13 @@ struct State5 {
 struct StepInv2 {
     f2 cdF, sdF, cdR, sdR;   // cos / sin of the steering angles per pair
     f2 muFzF, muFzR;         // mu_max * Fz
-    f2 tqF, tqR;
+    f2 tqF, tqR;             // torque / Jw
 };
 
 // vehicle_model.py:220-425 on pairs.  sc = (sin, cos) of the stage yaw.
 template <bool K2, bool CS>
 __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
-                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, float &axc,
-                                              float &ayc)
+                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, f2 &acc_c)
 {
     const float U = s.uv.x, V = s.uv.y, wz = s.wy.x;
     const f2 U2 = f2{U, U}, V2 = f2{V, V}, wz2 = f2{wz, wz};
@@ -318,23 +319,20 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     const f2 sums = f2{sumx, sumy};                            // (sum Fx, sum Fy)
     const f2 cross = pk_cross(s.uv, s.wy);                     // (V wz, -U wz)
     k.uv = fma2(Q.inv_m, sums, cross);                         // (U_dot, V_dot)
-    const f2 accs = k.uv - cross;                              // :413-414 (axc, ayc)
-    axc = accs.x;
-    ayc = accs.y;
+    acc_c = k.uv - cross;                                      // :413-414 (axc, ayc)
     const f2 my = fma2(fyF, Q.ab_F, fyR * Q.ab_R);             // a fy_front - b fy_rear, per side
     const float wzdot = P.inv_Izz * ((my.x + my.y) + P.half_T * (sfx.y - sfx.x));
     k.wy = f2{wzdot, wz};
-    k.wf = fma2(-Q.rw, fxtF, c.tqF) * Q.inv_Jw;                // quirk Q2: tire-frame force in front,
-    k.wr = fma2(-Q.rw, fxR, c.tqR) * Q.inv_Jw;                 //           chassis-frame force at the rear
+    k.wf = fma2(Q.neg_rw_Jw, fxtF, c.tqF);                     // :379-382, quirk Q2: tire-frame force in front,
+    k.wr = fma2(Q.neg_rw_Jw, fxR, c.tqR);                      //           chassis-frame force at the rear
     k.xy = fma2(U2, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));     // :384-385 (U cy - V sy, U sy + V cy)
 }
 
 // FAST RK4 step (vehicle_model.py:427-445) on pairs; `ok` as in rk4_step.
 template <bool K2, bool CS>
 __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
-                                          const State5 &s, float ax, float ay, const float delta[4],
-                                          const float tq[4], const float mu[4], float h, State5 &sn, float &axn,
-                                          float &ayn)
+                                          const State5 &s, f2 axy, const float delta[4], const float tq[4],
+                                          const float mu[4], float h, State5 &sn, f2 &axy_n)
 {
     bool ok = true;
     StepInv2 c;
@@ -350,39 +348,39 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
             c.sdR = f2{d2.x, d3.x}; c.cdR = f2{d2.y, d3.y};
         }
         // :255-258 (quirk Q3), then mu_max * Fz (quirk Q1)
-        const f2 ax2 = f2{ax, ax}, ay2 = f2{ay, ay};
+        const f2 ax2 = f2{axy.x, axy.x}, ay2 = f2{axy.y, axy.y};
         const f2 FzF = fma2(Q.dfyF, ay2, fma2(Q.dfxF, ax2, Q.Fz0F));
         const f2 FzR = fma2(Q.dfyR, ay2, fma2(Q.dfxR, ax2, Q.Fz0R));
         c.muFzF = f2{mu[0], mu[1]} * FzF;
         c.muFzR = f2{mu[2], mu[3]} * FzR;
-        c.tqF = f2{tq[0], tq[1]};
-        c.tqR = f2{tq[2], tq[3]};
+        c.tqF = f2{tq[0], tq[1]} * Q.inv_Jw;
+        c.tqR = f2{tq[2], tq[3]} * Q.inv_Jw;
     }
     const float hh = 0.5f * h;
     const f2 hh2 = splat(hh), h2 = splat(h), two = splat(2.0f);
-    float a1, a2, asx, asy;
+    f2 a, as2;
     const f2 sc0 = sincos_mid2(K, s.wy.y, ok);
     f2 sc;
     State5 k, acc, st;
 
 #define VDYN_S5_EACH(OP) OP(uv) OP(wy) OP(wf) OP(wr) OP(xy)
-    planar_deriv2<K2, CS>(P, Q, K, c, s, sc0, k, a1, a2);                    // K1
-    asx = a1; asy = a2;
+    planar_deriv2<K2, CS>(P, Q, K, c, s, sc0, k, a);                        // K1
+    as2 = a;
 #define VDYN_S5_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_1)
     sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a1, a2);                     // K2
-    asx = ::fmaf(2.0f, a1, asx); asy = ::fmaf(2.0f, a2, asy);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a);                        // K2
+    as2 = fma2(two, a, as2);
 #define VDYN_S5_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_2)
     sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a1, a2);                     // K3
-    asx = ::fmaf(2.0f, a1, asx); asy = ::fmaf(2.0f, a2, asy);
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a);                        // K3
+    as2 = fma2(two, a, as2);
 #define VDYN_S5_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_3)
     sc = stage_sincos2(K, sc0, h * k.wy.y, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a1, a2);                     // K4
-    asx += a1; asy += a2;
+    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a);                        // K4
+    as2 = as2 + a;
     const float sixth = 1.0f / 6.0f;
     const f2 h6 = splat(h * sixth);
 #define VDYN_S5_4(f) sn.f = fma2(h6, acc.f + k.f, s.f);
@@ -392,8 +390,7 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
 #undef VDYN_S5_3
 #undef VDYN_S5_4
 #undef VDYN_S5_EACH
-    axn = asx * sixth;
-    ayn = asy * sixth;
+    axy_n = as2 * splat(sixth);
     return ok;
 }
 
@@ -436,7 +433,10 @@ struct StepEngine<float> {
         S.wr = f2{s[5], s[6]};
         S.xy = f2{s[8], s[9]};
         float axn, ayn;
-        const bool ok = rk4_step2<K2, CS>(P, Q, K, S, ax, ay, delta, tq, mu, h, Sn, axn, ayn);
+        f2 axy_n;
+        const bool ok = rk4_step2<K2, CS>(P, Q, K, S, f2{ax, ay}, delta, tq, mu, h, Sn, axy_n);
+        axn = axy_n.x;
+        ayn = axy_n.y;
         if (__builtin_expect(__any(!ok) != 0, 0)) {
             if (!ok) {
                 float sn[10];
