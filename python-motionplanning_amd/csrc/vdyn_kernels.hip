@@ -90,7 +90,9 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             }
             __syncthreads();
         }
-        auto one_step = [&](int tc) __attribute__((always_inline)) {
+        // (two steps per trip, to save the ten v_mov that carry the state around the SAFE-redo
+        // branch, was measured: no gain, 0.3068 vs 0.3054 ms)
+        for (int tc = 0; tc < tc_n; ++tc) {
             const int t = t0 + tc;
             Ctrl<T, K> c;
             if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
@@ -107,10 +109,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 row[10 * n] = ax;
                 row[11 * n] = ay;
             }
-        };
-        // (two steps per trip, to save the ten v_mov that carry the state around the SAFE-redo
-        // branch, was measured: no gain, 0.3068 vs 0.3054 ms)
-        for (int tc = 0; tc < tc_n; ++tc) one_step(tc);
+        }
     }
 
     if (active) {
@@ -169,7 +168,7 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);
     StepEngine<T> eng;
-    eng.init(P);
+    eng.template init<false>(P);   // per-lane constants
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
@@ -332,12 +331,12 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
 
 // Config-5 MPC selection.  Block = one ego; lanes stride over the C shared
 // candidates; cost and (min, argmin) never leave the chip until the final pair.
-// Workgroup size and occupancy target.  fp32: 512 threads at 4 waves per SIMD (128 registers;
-// the step needs 135, the 16-byte spill costs less than the lost wave: 0.65 vs 0.70 ms on
-// config 5).  fp64: 256 threads, one wave per SIMD with the full register file (no spill;
-// at 128 registers the fp64 step spilled 700 bytes per lane).
+// Workgroup size and occupancy target.  fp32: 512 threads at 2 waves per SIMD -- the packed step
+// (vdyn_packed.hpp) holds its coefficient pairs in ~200 VGPRs and spilled 300 bytes per lane under
+// the 128-register cap of 4 waves per SIMD.  fp64: 256 threads, one wave per SIMD with the full
+// register file (no spill; at 128 registers the fp64 step spilled 700 bytes per lane).
 template <typename T> constexpr int mpc_block_max() { return sizeof(T) == 4 ? 512 : 256; }
-template <typename T> constexpr int mpc_waves_per_simd() { return sizeof(T) == 4 ? 4 : 1; }
+template <typename T> constexpr int mpc_waves_per_simd() { return sizeof(T) == 4 ? 2 : 1; }
 
 template <typename T, bool CS>
 __global__ void __launch_bounds__(mpc_block_max<T>(), mpc_waves_per_simd<T>())

@@ -96,26 +96,41 @@ struct PkConsts {
 
 // Vehicle constants as pairs (front axle pair F = (FL, FR), rear pair R = (RL, RR)).
 struct PkParams {
-    f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw, a_b;   // a_b = (a, a) for the front pair use, see below
+    f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw;
     f2 ab_F, ab_R;                                       // (+a, +a), (-b, -b): lever arms of the pairs
     f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
     f2 neg_rw_Jw;                                        // -rw / Jw
     f2 Fz0F, Fz0R, dfxF, dfyF, dfxR, dfyR;               // static loads and load-transfer coefficients per pair (:255-258)
+    // UNIFORM: P is the same for every lane (a by-value kernel argument, in SGPRs); otherwise it was
+    // read per lane (heterogeneous fleet, VGPRs).
+    template <bool UNIFORM>
     __device__ __forceinline__ void init(const DevParams<float> &P)
     {
         BF = f2{P.B[0], P.B[1]}; BR = f2{P.B[2], P.B[3]};
         invBF = f2{P.invB[0], P.invB[1]}; invBR = f2{P.invB[2], P.invB[3]};
         CF = f2{P.C[0], P.C[1]}; CR = f2{P.C[2], P.C[3]};
-        rw = splat(P.rw); inv_Jw = splat(P.inv_Jw);
-        ab_F = splat(P.a); ab_R = splat(-P.b);
-        a_b = f2{P.a, P.b};
-        a_negb = f2{P.a, -P.b};
-        hT_side = f2{-P.half_T, P.half_T};
-        inv_m = splat(P.inv_m);
-        neg_rw_Jw = splat(-P.rw * P.inv_Jw);
-        Fz0F = splat(P.Fz0F); Fz0R = splat(P.Fz0R);
-        dfxF = f2{-P.DfzxL, -P.DfzxR}; dfyF = f2{-P.DfzyF, P.DfzyF};
-        dfxR = f2{P.DfzxL, P.DfzxR}; dfyR = f2{-P.DfzyR, P.DfzyR};
+        // Scalars first, each behind a zero-instruction barrier: left visible as neighbouring struct
+        // fields, pairs of them are fetched with one 8-byte read, and because such reads overlap
+        // (inv_Jw|a, a|b) the compiler then parks that part of the by-value struct in scratch.
+        float a = P.a, b = P.b, iJw = P.inv_Jw, dxl = P.DfzxL, dxr = P.DfzxR, dyf = P.DfzyF, dyr = P.DfzyR,
+              r_w = P.rw, f0f = P.Fz0F, f0r = P.Fz0R, hT = P.half_T, im = P.inv_m;
+        if (UNIFORM)   // stay in SGPRs: a scalar source operand costs the packed op no VGPR read port
+            asm("" : "+s"(a), "+s"(b), "+s"(iJw), "+s"(dxl), "+s"(dxr), "+s"(dyf), "+s"(dyr), "+s"(r_w), "+s"(f0f),
+                "+s"(f0r), "+s"(hT), "+s"(im));
+        else
+            asm("" : "+v"(a), "+v"(b), "+v"(iJw), "+v"(dxl), "+v"(dxr), "+v"(dyf), "+v"(dyr), "+v"(r_w), "+v"(f0f),
+                "+v"(f0r), "+v"(hT), "+v"(im));
+        rw = splat(r_w); inv_Jw = splat(iJw);
+        ab_F = splat(a); ab_R = splat(-b);
+        a_negb = f2{a, -b};
+        hT_side = f2{-hT, hT};
+        inv_m = splat(im);
+        neg_rw_Jw = splat(-r_w * iJw);
+        Fz0F = splat(f0f); Fz0R = splat(f0r);
+        dfxF = f2{-dxl, -dxr}; dfyF = f2{-dyf, dyf};
+        dfxR = f2{dxl, dxr}; dfyR = f2{-dyr, dyr};
+        // used once per step: keep them in VGPRs, the SGPR file is already full of DevParams
+        asm volatile("" : "+v"(Fz0F), "+v"(Fz0R), "+v"(dfxF), "+v"(dfyF), "+v"(dfxR), "+v"(dfyR), "+v"(neg_rw_Jw));
     }
 };
 
@@ -403,6 +418,7 @@ namespace vdyn {
 // fp64 has no packed VALU form and goes through rk4_advance.
 template <typename T>
 struct StepEngine {
+    template <bool UNIFORM = true>
     __device__ __forceinline__ void init(const DevParams<T> &) {}
     template <bool K2, bool CS>
     __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
@@ -416,10 +432,11 @@ template <>
 struct StepEngine<float> {
     PkConsts K;
     PkParams Q;
+    template <bool UNIFORM = true>
     __device__ __forceinline__ void init(const DevParams<float> &P)
     {
         K.init();
-        Q.init(P);
+        Q.init<UNIFORM>(P);
     }
     template <bool K2, bool CS>
     __device__ __forceinline__ void advance(const DevParams<float> &P, float s[10], float &ax, float &ay,
