@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="fixed 65536 rollouts split over the ranks (BASELINE configs[3] as worded) instead "
                          "of the default weak scaling; small shards use the wheel-parallel kernel")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N>1 code path (RCCL all-gather of terminal states, overlapped with the "
+                         "next launch) even with one rank: rehearsal of the multi-GPU path on a 1-GPU box")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="wait for each all-gather before the next launch (A/B of the overlap)")
     return ap.parse_args()
 
 
@@ -142,9 +147,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     pkg = importlib.import_module("python-motionplanning_amd")
     W = pkg.workloads
@@ -158,10 +167,15 @@ def main():
     s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
     pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
-    gathered = torch.empty((world * 12, n_local), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * 12, n_local), dtype=torch.float32, device=dev) if collective else None
     del s0_all, pid_all
 
     kern_ev = []
+    pending = []   # [(work, terminal)] of the all-gather in flight; the tensor stays referenced until waited for
+
+    def drain():
+        while pending:
+            pending.pop()[0].wait()
 
     def step(record):
         if record:
@@ -171,12 +185,20 @@ def main():
         if record:
             b.record()
             kern_ev.append((a, b))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, term)
+        if collective:
+            # the exchange step of BASELINE configs[3]: every rank ends up with all terminal states.
+            # RCCL runs it on its own stream; the previous step's gather is only waited for AFTER this
+            # step's rollout has been queued, so gather k overlaps rollout k+1 (all K gathers still
+            # complete inside the timed region: fence() drains the last one)
+            drain()
+            pending.append((dist.all_gather_into_tensor(gathered, term, async_op=True), term))
+            if args.no_overlap:
+                drain()
         return term
 
     def fence():
-        if world > 1:
+        drain()
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,6 +208,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         term = step(True)
+    enqueue = time.perf_counter() - t0     # host time to queue the K steps (GPU-bound when << elapsed)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -204,10 +227,11 @@ def main():
         "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rollouts_per_s": world * n_local * args.steps / elapsed,
+        "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
         "config": {
             "workload": "BASELINE configs[2]: 65536 rollouts per GPU (ego r//7, lattice path r%7) x 200 "
                         "RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared via LDS; "
-                        "N>1: + RCCL all-gather of terminal states [12][65536] per rank",
+                        "N>1: + RCCL all-gather of terminal states [12][65536] per rank, gather k overlapped with rollout k+1",
             "rollouts_per_gpu": n_local, "horizon": HORIZON, "dt": DT, "controls": "shared[7][200][2]",
         },
     }
@@ -250,7 +274,7 @@ def main():
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["value"] / cb["value"]
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
