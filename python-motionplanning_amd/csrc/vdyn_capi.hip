@@ -22,6 +22,8 @@ struct VdynHandle {
     int lanes_per_rollout = 1;      // VDYN_OPT_LANES_PER_ROLLOUT
     void *d_fleet = nullptr;        // device copy of the per-class constants of the last fleet call
     size_t d_fleet_bytes = 0;
+    void *d_aux = nullptr;          // controllers' auxiliary waypoint tables (segment lengths, bounding circles)
+    size_t d_aux_bytes = 0;
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -160,6 +162,7 @@ void vdyn_destroy(VdynHandle *h)
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->h_mapped) (void)hipHostFree(h->h_mapped);
     if (h->d_fleet) (void)hipFree(h->d_fleet);
+    if (h->d_aux) (void)hipFree(h->d_aux);
     delete h;
 }
 
@@ -499,8 +502,22 @@ int closed_loop_dev(VdynHandle *h, const VdynCtrlGains *g, const vdyn::ClosedLoo
     int rc = closed_loop_check<T>(h, g, a, update_only, who);
     if (rc || a.n == 0) return rc;
     VDYN_HIP(h, hipSetDevice(h->device));
-    if (update_only) VDYN_HIP(h, vdyn::launch_controller_update<T>(*g, a, (hipStream_t)stream));
-    else VDYN_HIP(h, vdyn::launch_closed_loop<T>(h->p, *g, a, (hipStream_t)stream));
+    // tables too large for LDS: segment lengths + bounding circles in a handle-owned device buffer
+    // (grown on demand; hipFree waits for the launches still reading the old one)
+    vdyn::ClosedLoopArgs<T> b = a;
+    const size_t aux_bytes = vdyn::closed_loop_aux_bytes<T>(a.P, a.Wmax, update_only);
+    if (aux_bytes > h->d_aux_bytes) {
+        if (h->d_aux) { (void)hipFree(h->d_aux); h->d_aux = nullptr; h->d_aux_bytes = 0; }
+        if (hipMalloc(&h->d_aux, aux_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_aux = nullptr;               // no room: the kernels fall back to the plain full scan
+        } else {
+            h->d_aux_bytes = aux_bytes;
+        }
+    }
+    b.aux = aux_bytes > 0 && h->d_aux_bytes >= aux_bytes ? static_cast<T *>(h->d_aux) : nullptr;
+    if (update_only) VDYN_HIP(h, vdyn::launch_controller_update<T>(*g, b, (hipStream_t)stream));
+    else VDYN_HIP(h, vdyn::launch_closed_loop<T>(h->p, *g, b, (hipStream_t)stream));
     return VDYN_OK;
 }
 

@@ -63,13 +63,24 @@ constexpr int kWpBlock = 32;  // waypoints per bounding circle
 template <typename T>
 struct Waypoints {
     const T *base;    // this lane's table: [W][2]
-    const T *seg;     // nullable: [W] segment lengths of the same table
-    const T *bounds;  // nullable: [ceil(W / 32)][4] = centre x, y, radius (inflated), unused
+    const T *seg;     // nullable: segment lengths of the same table, seg[i * ss]
+    const T *bounds;  // nullable: bounding circles, component c of block b at bounds[(4 * b + c) * bs]:
+                      //           centre x, y, radius (inflated), unused
     int W;
+    int ss, bs;       // element strides: 1 for a table staged in LDS; the number of tables when the
+                      // auxiliary arrays live in global memory TRANSPOSED ([i][P], [b][4][P]), so that
+                      // the lanes of a wave -- vehicles with consecutive tables -- read neighbouring words
     __device__ __forceinline__ void get(int i, T &x, T &y) const
     {
         x = base[2 * i];
         y = base[2 * i + 1];
+    }
+    __device__ __forceinline__ T seg_at(int i) const { return seg[(int64_t)i * ss]; }
+    __device__ __forceinline__ void bound(int b, T &cx, T &cy, T &r) const
+    {
+        cx = bounds[(int64_t)(4 * b) * bs];
+        cy = bounds[(int64_t)(4 * b + 1) * bs];
+        r = bounds[(int64_t)(4 * b + 2) * bs];
     }
 };
 
@@ -153,16 +164,31 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, 
     ambiguous = false;
     T best_d = T(INFINITY);
     const int nb = (wp.W + kWpBlock - 1) / kWpBlock;
-    for (int b = 0; b < nb; ++b) {
-        const T cx = wp.bounds[4 * b], cy = wp.bounds[4 * b + 1], r = wp.bounds[4 * b + 2];
-        const T ex = cx - x, ey = cy - y;
-        const T dq = L::sqrt(ex * ex + ey * ey);
-        const bool need = !(dq * T(0.999999) - r > best_d);       // when in doubt, scan
-        if (__any(need)) {
-            if (need) {
-                nearest_in_range<T, EXACT>(wp, b * kWpBlock, min((b + 1) * kWpBlock, wp.W), x, y, best_d2, best_i,
-                                           ambiguous);
-                best_d = L::sqrt(best_d2);
+    // Eight circles per trip: their reads go out together (one latency instead of eight) and the
+    // test "can block b hold a point as near as the running minimum", |q - c| - r <= best_d, is
+    // evaluated without a root as |q - c|^2 <= (best_d + r)^2, with the left side shrunk by 2e-6
+    // so that rounding can only make a block look nearer (when in doubt, scan).
+    constexpr int kChunk = 8;
+    for (int b0 = 0; b0 < nb; b0 += kChunk) {
+        T dq2[kChunk], rr[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            T cx, cy;
+            wp.bound(min(b0 + j, nb - 1), cx, cy, rr[j]);
+            const T ex = cx - x, ey = cy - y;
+            dq2[j] = (ex * ex + ey * ey) * T(0.999998);
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            const int b = b0 + j;
+            const T reach = best_d + rr[j];
+            const bool need = b < nb && !(dq2[j] > reach * reach);
+            if (__any(need)) {
+                if (need) {
+                    nearest_in_range<T, EXACT>(wp, b * kWpBlock, min((b + 1) * kWpBlock, wp.W), x, y, best_d2,
+                                               best_i, ambiguous);
+                    best_d = L::sqrt(best_d2);
+                }
             }
         }
     }
@@ -200,7 +226,7 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
         for (int i0 = best_i + 1; i0 < wp.W && !done; i0 += 8) {
             T sg[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sg[k] = wp.seg[min(i0 + k, wp.W - 1)];
+            for (int k = 0; k < 8; ++k) sg[k] = wp.seg_at(min(i0 + k, wp.W - 1));
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const bool take = !done && (i0 + k) < wp.W;

@@ -70,6 +70,7 @@ struct ClosedLoopArgs {
     T *log = nullptr;             // nullable [H][16][n]
     T *datalog = nullptr;         // nullable [H][45][n]: the reference's DataLog columns
     T *ctrl_out = nullptr;        // controller_update only: [3][n]
+    T *aux = nullptr;             // device scratch of closed_loop_aux_bytes() bytes (nullable: plain scan)
 };
 
 template <typename T>
@@ -77,6 +78,8 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
                               hipStream_t st);
 template <typename T>
 hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs<T> &a, hipStream_t st);
+template <typename T>
+size_t closed_loop_aux_bytes(int P, int Wmax, bool update_only);
 
 template <typename T>
 struct SelectArgs {

@@ -396,6 +396,81 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
     }
 }
 
+// Auxiliary waypoint tables for the controllers when the P tables do not fit LDS: segment lengths
+// seg[j][P] and one bounding circle per 32 waypoints bnd[b][4][P], both TRANSPOSED (table index
+// fastest) so that the lanes of a wave -- vehicles with consecutive tables -- read neighbouring
+// words.  aux = seg (Wmax * P) followed by bnd (nb * 4 * P).
+// One workgroup per tile of kAuxTP tables x kAuxTJ waypoints: the tile is read along the tables'
+// own rows (contiguous), kept in LDS, and written out table-index-fastest (contiguous again).
+constexpr int kAuxTP = 32;                 // tables per tile
+constexpr int kAuxTJ = 2 * kWpBlock;       // waypoints per tile = two bounding circles per table
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ wcount, int Pn, T *__restrict__ aux)
+{
+    __shared__ T tx[kAuxTP][kAuxTJ + 2], ty[kAuxTP][kAuxTJ + 2];   // column 0 = the waypoint before the tile
+    const int nb = (Wmax + kWpBlock - 1) / kWpBlock;
+    T *seg = aux, *bnd = aux + (int64_t)Wmax * Pn;
+    const int tiles_j = (Wmax + kAuxTJ - 1) / kAuxTJ;
+    const int p0 = (blockIdx.x / tiles_j) * kAuxTP, j0 = (blockIdx.x % tiles_j) * kAuxTJ;
+    // read: thread -> (table row, waypoint) with the waypoint fastest
+    for (int i = threadIdx.x; i < kAuxTP * (kAuxTJ + 1); i += kBlock) {
+        const int pp = i / (kAuxTJ + 1), jj = i - pp * (kAuxTJ + 1);      // jj = 0 is waypoint j0 - 1
+        const int p = p0 + pp, j = j0 + jj - 1;
+        T x = T(0), y = T(0);
+        if (p < Pn && j >= 0 && j < Wmax) {
+            const T *q = wp + ((int64_t)p * Wmax + j) * 2;
+            x = q[0];
+            y = q[1];
+        }
+        tx[pp][jj] = x;
+        ty[pp][jj] = y;
+    }
+    __syncthreads();
+    // segment lengths: thread -> (waypoint, table) with the table fastest
+    for (int i = threadIdx.x; i < kAuxTP * kAuxTJ; i += kBlock) {
+        const int jj = i / kAuxTP, pp = i - jj * kAuxTP;
+        const int p = p0 + pp, j = j0 + jj;
+        if (p < Pn && j < Wmax)
+            seg[(int64_t)j * Pn + p] = j == 0 ? T(0) : segment_length<T>(tx[pp][jj], ty[pp][jj], tx[pp][jj + 1], ty[pp][jj + 1]);
+    }
+    // bounding circles: one thread per (table, block of 32 waypoints) of the tile
+    if (threadIdx.x < kAuxTP * (kAuxTJ / kWpBlock)) {
+        const int bb = threadIdx.x / kAuxTP, pp = threadIdx.x - bb * kAuxTP;
+        const int p = p0 + pp, b = j0 / kWpBlock + bb;
+        if (p < Pn && b < nb) {
+            const int W = min(max(wcount[p], 1), Wmax);
+            const int lo = b * kWpBlock, hi = min(lo + kWpBlock, W);
+            T x0 = T(INFINITY), x1 = -T(INFINITY), y0 = T(INFINITY), y1 = -T(INFINITY);
+            for (int j = lo; j < hi; ++j) {
+                const T wx = tx[pp][j - j0 + 1], wy = ty[pp][j - j0 + 1];
+                x0 = wx < x0 ? wx : x0; x1 = wx > x1 ? wx : x1;
+                y0 = wy < y0 ? wy : y0; y1 = wy > y1 ? wy : y1;
+            }
+            const T cx = T(0.5) * (x0 + x1), cy = T(0.5) * (y0 + y1);
+            T r2 = T(0);
+            for (int j = lo; j < hi; ++j) {
+                const T dx = tx[pp][j - j0 + 1] - cx, dy = ty[pp][j - j0 + 1] - cy;
+                const T d2 = dx * dx + dy * dy;
+                r2 = d2 > r2 ? d2 : r2;
+            }
+            const bool empty = lo >= hi;                                   // a block past the table's end: never entered
+            bnd[((int64_t)4 * b + 0) * Pn + p] = empty ? T(0) : cx;
+            bnd[((int64_t)4 * b + 1) * Pn + p] = empty ? T(0) : cy;
+            bnd[((int64_t)4 * b + 2) * Pn + p] = empty ? T(0) : Lib<T>::sqrt(r2) * T(1.00001) + T(1e-30);
+            bnd[((int64_t)4 * b + 3) * Pn + p] = T(0);
+        }
+    }
+}
+
+template <typename T>
+size_t waypoint_aux_len(int P, int Wmax)
+{
+    const size_t nb = (size_t)(Wmax + kWpBlock - 1) / kWpBlock;
+    return (size_t)Wmax * P + nb * 4 * P;
+}
+
 // Closed-loop rollout: the sub-step loop of drive.py:114-151 without the planner.  Every
 // `ctrl_every` steps the lane runs the Stanley + PID + filter update (vdyn_controls.hpp)
 // against its waypoint table, holds the commands in between (zero-order hold, drive.py:128)
@@ -412,7 +487,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
                    const T *__restrict__ state0, const T *__restrict__ cstate0, const T *__restrict__ wp,
                    int Wmax, const int *__restrict__ wcount, const int *__restrict__ path_id, int Pn, T h,
                    T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log,
-                   T *__restrict__ datalog)
+                   T *__restrict__ datalog, const T *__restrict__ aux)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS image: P tables of (x, y) pairs, then P tables of segment lengths; each table is
@@ -479,8 +554,10 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     const int pid = min(max(path_id[r], 0), Pn - 1);
     Waypoints<T> w;
     w.base = WPLDS ? lds_wp + (int64_t)pid * wstride * 2 : wp + (int64_t)pid * Wmax * 2;
-    w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : nullptr;
-    w.bounds = WPLDS ? lds_bnd + (int64_t)pid * nbmax * 4 : nullptr;
+    // not in LDS: the transposed global tables of waypoint_aux_kernel (nullptr: plain full scan)
+    w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : (aux != nullptr ? aux + pid : nullptr);
+    w.bounds = WPLDS ? lds_bnd + (int64_t)pid * nbmax * 4 : (aux != nullptr ? aux + (int64_t)Wmax * Pn + pid : nullptr);
+    w.ss = w.bs = WPLDS ? 1 : Pn;
     w.W = min(max(wcount[pid], 1), Wmax);
     StepEngine<T> eng;
     if (!DATALOG) eng.init(P);
@@ -543,7 +620,8 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 controller_kernel(CtrlGains<T> G, int64_t n, const T *__restrict__ state, const T *__restrict__ cstate0,
                   const T *__restrict__ wp, int Wmax, const int *__restrict__ wcount,
-                  const int *__restrict__ path_id, int Pn, T h, T *__restrict__ cstate, T *__restrict__ out)
+                  const int *__restrict__ path_id, int Pn, T h, T *__restrict__ cstate, T *__restrict__ out,
+                  const T *__restrict__ aux)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
@@ -560,8 +638,9 @@ controller_kernel(CtrlGains<T> G, int64_t n, const T *__restrict__ state, const 
     const int pid = min(max(path_id[r], 0), Pn - 1);
     Waypoints<T> w;
     w.base = wp + (int64_t)pid * Wmax * 2;
-    w.seg = nullptr;
-    w.bounds = nullptr;
+    w.seg = aux != nullptr ? aux + pid : nullptr;
+    w.bounds = aux != nullptr ? aux + (int64_t)Wmax * Pn + pid : nullptr;
+    w.ss = w.bs = Pn;
     w.W = min(max(wcount[pid], 1), Wmax);
     T steer;
     controller_update<T>(G, w, s, h, c, steer);
@@ -666,22 +745,61 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
     }
 }
 
-// Lattice generation, stage 1: one lane per ego -- closest and goal index on the global path
-// (local_planner.py:25-52, :85-152).
+// Lattice generation, stage 1: closest and goal index on the global path (local_planner.py:25-52,
+// :85-152).  One workgroup per ego.  The reference's sequential scan keeps the LAST index whose rounded
+// distance equals the minimum ('<=' on the sqrt values, local_planner.py:44-50); sqrt is monotone,
+// so that is: m = sqrt(min d^2), answer = max { i : sqrt(d_i^2) <= m } -- two strided passes
+// (coalesced reads of the shared path) and two workgroup reductions instead of a 4000-step chain
+// per lane.  Only candidates within 16 ulp of the minimum take the root in the second pass.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 lattice_index_kernel(int E, const T *__restrict__ px, const T *__restrict__ py, int nwp, const T *__restrict__ ego,
                      T lookahead, int *__restrict__ closest_idx, int *__restrict__ goal_idx,
                      T *__restrict__ closest_len)
 {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= E) return;
-    int ci;
-    T len;
-    closest_index<T>(px, py, nwp, ego[e], ego[(int64_t)E + e], ci, len);
-    closest_idx[e] = ci;
-    if (closest_len != nullptr) closest_len[e] = len;
-    goal_idx[e] = goal_index<T>(px, py, nwp, lookahead, len, ci);
+    __shared__ T s_min[kBlock / 64];
+    __shared__ int s_idx[kBlock / 64];
+    const int e = blockIdx.x;
+    const T ex = ego[e], ey = ego[(int64_t)E + e];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    T m2 = T(INFINITY);
+    for (int i = threadIdx.x; i < nwp; i += kBlock) {
+        const T dx = px[i] - ex, dy = py[i] - ey;
+        const T d2 = dx * dx + dy * dy;
+        m2 = d2 < m2 ? d2 : m2;                       // NaN never wins, as in the reference
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(m2, off);
+        m2 = o < m2 ? o : m2;
+    }
+    if (lane == 0) s_min[wave] = m2;
+    __syncthreads();
+    m2 = s_min[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) m2 = s_min[w] < m2 ? s_min[w] : m2;
+    const T m = Lib<T>::sqrt(m2);
+
+    int bi = -1;
+    const T band = m2 * (T(2) - Lib<T>::kTieBand);   // 1 + 16 ulp
+    for (int i = threadIdx.x; i < nwp; i += kBlock) {
+        const T dx = px[i] - ex, dy = py[i] - ey;
+        const T d2 = dx * dx + dy * dy;
+        if (d2 <= band && Lib<T>::sqrt(d2) <= m) bi = i;     // i grows along the loop: the last one stays
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bi = max(bi, __shfl_xor(bi, off));
+    if (lane == 0) s_idx[wave] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) bi = max(bi, s_idx[w]);
+        const int ci = bi < 0 ? 0 : bi;               // nothing comparable (all NaN): the reference's initial 0
+        closest_idx[e] = ci;
+        if (closest_len != nullptr) closest_len[e] = m;
+        goal_idx[e] = goal_index<T>(px, py, nwp, lookahead, m, ci);
+    }
 }
 
 // Stage 2: one lane per (ego, lateral offset) -- goal state (:154-275), spiral optimisation
@@ -978,6 +1096,9 @@ static CtrlGains<T> make_gains(const VdynCtrlGains &g)
     return c;
 }
 
+// gfx950 has 160 KiB of LDS per CU; the closed loop may take 152 KiB of it for waypoint tables
+constexpr size_t kClosedLoopLdsBudget = 152 * 1024;
+
 template <typename T>
 hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const ClosedLoopArgs<T> &a,
                               hipStream_t st)
@@ -990,8 +1111,15 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     const size_t wp_bytes = ((size_t)a.P * (a.Wmax + 1) * 3 + (size_t)a.P * ((a.Wmax + kWpBlock - 1) / kWpBlock) * 4) * sizeof(T);
     // gfx950 has 160 KiB of LDS per CU; a workgroup may take all of it (one workgroup per
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
-    const bool lds = wp_bytes <= 152 * 1024;
+    const bool lds = wp_bytes <= kClosedLoopLdsBudget;
     const bool cs = shape_factors_small(p);
+    if (!lds && a.aux != nullptr) {
+        const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
+        hipLaunchKernelGGL((waypoint_aux_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
+                           a.wcount, a.P, a.aux);
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return e_;
+    }
 #define VDYN_CL2(CSV, LDSV, DLV)                                                                      \
     {                                                                                                 \
         if (LDSV && wp_bytes > 64 * 1024) {                                                           \
@@ -1003,7 +1131,7 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
         hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV>), dim3(grid), dim3(kBlock),         \
                            LDSV ? wp_bytes : 0, st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0,  \
                            a.cstate0, a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.terminal,    \
-                           a.cstate, a.log, a.datalog);                                               \
+                           a.cstate, a.log, a.datalog, LDSV ? (const T *)nullptr : (const T *)a.aux); \
     }
 #define VDYN_CL(CSV, LDSV)                                                                            \
     if (a.datalog != nullptr) VDYN_CL2(CSV, LDSV, true) else VDYN_CL2(CSV, LDSV, false)
@@ -1016,14 +1144,33 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     return hipGetLastError();
 }
 
+// Bytes of device scratch the controllers want for (P tables x Wmax waypoints): 0 when the closed
+// loop stages the tables in LDS; the single controller update has no LDS stage and asks for it
+// once the plain full scan would be the slower choice.
+template <typename T>
+size_t closed_loop_aux_bytes(int P, int Wmax, bool update_only)
+{
+    const size_t wp_bytes = ((size_t)P * (Wmax + 1) * 3 + (size_t)P * ((Wmax + kWpBlock - 1) / kWpBlock) * 4) * sizeof(T);
+    if (!update_only && wp_bytes <= kClosedLoopLdsBudget) return 0;
+    if (update_only && Wmax < 4 * kWpBlock) return 0;
+    return waypoint_aux_len<T>(P, Wmax) * sizeof(T);
+}
+
 template <typename T>
 hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs<T> &a, hipStream_t st)
 {
     if (a.n <= 0) return hipSuccess;
     const CtrlGains<T> G = make_gains<T>(g);
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    if (a.aux != nullptr) {
+        const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
+        hipLaunchKernelGGL((waypoint_aux_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
+                           a.wcount, a.P, a.aux);
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return e_;
+    }
     hipLaunchKernelGGL((controller_kernel<T>), dim3(grid), dim3(kBlock), 0, st, G, a.n, a.state0, a.cstate0,
-                       a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.cstate, a.ctrl_out);
+                       a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.cstate, a.ctrl_out, (const T *)a.aux);
     return hipGetLastError();
 }
 
@@ -1049,7 +1196,7 @@ template <typename T>
 hipError_t launch_plan_lattice(const LatticeArgs<T> &a, hipStream_t st)
 {
     if (a.E <= 0) return hipSuccess;
-    hipLaunchKernelGGL((lattice_index_kernel<T>), dim3((unsigned)((a.E + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+    hipLaunchKernelGGL((lattice_index_kernel<T>), dim3((unsigned)a.E), dim3(kBlock), 0, st,
                        a.E, a.px, a.py, a.nwp, a.ego, (T)a.lookahead, a.closest_idx, a.goal_idx, a.closest_len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1079,6 +1226,7 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     template hipError_t launch_closed_loop<T>(const VdynParams &, const VdynCtrlGains &,             \
                                               const ClosedLoopArgs<T> &, hipStream_t);               \
     template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t); \
+    template size_t closed_loop_aux_bytes<T>(int, int, bool);                                        \
     template hipError_t launch_select_best_path<T>(const SelectArgs<T> &, hipStream_t);             \
     template hipError_t launch_rollout_fleet<T>(const RolloutArgs<T> &, bool, hipStream_t);          \
     template void build_fleet_table<T>(const VdynParams *, int, const double *, T *, bool *);        \
