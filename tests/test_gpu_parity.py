@@ -636,6 +636,45 @@ def test_g11_lattice_generation(gpu_vm, oracle):
     assert wc2[0] == 0 and wc2[1] == 0 and wc2[2] == 0                  # none selected / table too small
 
 
+def test_closest_index_ties_and_edges(gpu_vm, oracle):
+    """get_closest_index keeps the LAST of equal minima ('<=', local_planner.py:44-50); the device
+    finds it with a parallel two-pass argmin.  Exact ties (duplicated waypoints, an ego equidistant
+    from several waypoints), a NaN waypoint and a one-point path against the oracle's sequential scan."""
+    vm = gpu_vm(1e-3)
+    O = oracle
+    L = O.lib()
+    import ctypes as C
+
+    def seq(px, py, ex, ey):
+        clen = C.c_double()
+        L.oracle_closest_index_f64.restype = C.c_int
+        ci = L.oracle_closest_index_f64(px.ctypes.data_as(C.c_void_p), py.ctypes.data_as(C.c_void_p), C.c_int(px.size),
+                                        C.c_double(ex), C.c_double(ey), C.byref(clen))
+        return ci, clen.value
+
+    rng = np.random.default_rng(11)
+    # 600 points on a grid-aligned polyline with every third point duplicated later in the list
+    base = np.stack([np.arange(200) * 0.5, np.round(np.sin(np.arange(200) * 0.1) * 4) * 0.5])
+    px = np.concatenate([base[0], base[0][::3], base[0][::2]])
+    py = np.concatenate([base[1], base[1][::3], base[1][::2]])
+    E = 300
+    k = rng.integers(0, 200, E)
+    ego = np.stack([base[0][k] + rng.choice([0.0, 0.25, 0.5], E), base[1][k] + rng.choice([0.0, 0.25, -0.25], E),
+                    np.zeros(E)])
+    dev = vm.plan_lattice(px, py, ego, 25.0)
+    for e in range(E):
+        ci, cl = seq(px, py, ego[0, e], ego[1, e])
+        assert dev["closest_index"][e] == ci, (e, dev["closest_index"][e], ci)
+    # a NaN waypoint never wins and does not disturb the rest; a single-point path returns index 0
+    pxn, pyn = px.copy(), py.copy()
+    pxn[17] = np.nan
+    devn = vm.plan_lattice(pxn, pyn, ego[:, :64].copy(), 25.0)
+    for e in range(64):
+        assert devn["closest_index"][e] == seq(pxn, pyn, ego[0, e], ego[1, e])[0]
+    one = vm.plan_lattice(np.array([1.0, 2.0]), np.array([0.0, 0.0]), np.array([[5.0], [1.0], [0.0]]), 25.0)
+    assert one["closest_index"][0] == 1 and one["goal_index"][0] == 1
+
+
 def test_lattice_optimiser_vs_scipy_on_seeded_goals(gpu_vm, oracle):
     """48 seeded goal states optimised by the reference (G11 direct_*), and 2000 egos spread along
     the global path against the oracle's SciPy-driven plan on a sample of them."""
