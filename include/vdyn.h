@@ -31,6 +31,9 @@
  * scratch and return after the results are in the caller's buffers.
  * The caller owns every buffer; the library never frees caller memory and never
  * writes an input.  A handle is not thread-safe; distinct handles are independent.
+ * A handle also owns small device work buffers (fleet constants, the controllers' auxiliary
+ * waypoint tables) that consecutive `_dev` calls reuse: enqueue the calls of one handle on ONE
+ * stream at a time (or order the streams yourself); use one handle per concurrent stream.
  * Non-finite values propagate as in the reference (vx = 0 divides by zero,
  * vehicle_model.py:284-293); there is no clamping.
  */
