@@ -149,26 +149,44 @@ __device__ __forceinline__ void nearest_in_range(const Waypoints<T> &wp, int lo,
     }
 }
 
-// The same global search, exactly, with most of the table skipped: every 32 consecutive
-// waypoints carry a bounding circle (centre c, radius r >= every member's distance to c), and a
-// block whose nearest possible member, |q - c| - r, is farther than the running minimum can hold
-// neither the minimum nor a tie with it.  Blocks are visited in order, so "first minimum wins"
-// is preserved; a wave descends into a block when any of its lanes needs it.
+// The same global search, exactly, with most of the table skipped.  Every 32 consecutive waypoints
+// carry a bounding circle (centre c, radius r >= every member's distance to c), so block b holds a
+// point within |q - c_b| + r_b of the query q and none nearer than |q - c_b| - r_b.
+//   pass 1: U = min_b (|q - c_b| + r_b), an upper bound of the minimum distance;
+//   pass 2: a block with |q - c_b| - r_b > U can hold neither the minimum nor a tie with it; the lane
+//           keeps [lo, hi], the first and last block that might;
+//   scan:   the reference's sequential scan (strict '<', first minimum wins) over the waypoints of
+//           blocks lo..hi only -- everything outside is strictly farther than the minimum, so the
+//           result is the one of the full scan.
+// Each lane scans ITS OWN range (typically 2-3 blocks around its vehicle): lanes of a wave that sit
+// at different places along the path do not pay for each other's blocks.  The bounds are read
+// eight at a time (one LDS / memory latency per eight circles); every inequality is slackened by
+// 1e-6 so that rounding can only widen the range (when in doubt, scan).
 template <typename T, bool EXACT>
 __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, T x, T y, T &best_d2, int &best_i,
                                                         bool &ambiguous)
 {
-    using L = Lib<T>;
     best_d2 = T(INFINITY);
     best_i = 0;
     ambiguous = false;
-    T best_d = T(INFINITY);
     const int nb = (wp.W + kWpBlock - 1) / kWpBlock;
-    // Eight circles per trip: their reads go out together (one latency instead of eight) and the
-    // test "can block b hold a point as near as the running minimum", |q - c| - r <= best_d, is
-    // evaluated without a root as |q - c|^2 <= (best_d + r)^2, with the left side shrunk by 2e-6
-    // so that rounding can only make a block look nearer (when in doubt, scan).
     constexpr int kChunk = 8;
+    T U = T(INFINITY);
+    for (int b0 = 0; b0 < nb; b0 += kChunk) {
+        T ub[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            T cx, cy, r;
+            wp.bound(min(b0 + j, nb - 1), cx, cy, r);
+            const T ex = cx - x, ey = cy - y;
+            // float root, inflated: an upper bound does not need the last bits
+            // (+1e-18: distances below the float range's root would otherwise round to zero)
+            ub[j] = (T)__builtin_sqrtf((float)(ex * ex + ey * ey)) * T(1.000001) + r + T(1e-18);
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) U = ub[j] < U ? ub[j] : U;     // NaN never lowers U
+    }
+    int lo = nb, hi = -1;
     for (int b0 = 0; b0 < nb; b0 += kChunk) {
         T dq2[kChunk], rr[kChunk];
 #pragma unroll
@@ -181,17 +199,14 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, 
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
             const int b = b0 + j;
-            const T reach = best_d + rr[j];
-            const bool need = b < nb && !(dq2[j] > reach * reach);
-            if (__any(need)) {
-                if (need) {
-                    nearest_in_range<T, EXACT>(wp, b * kWpBlock, min((b + 1) * kWpBlock, wp.W), x, y, best_d2,
-                                               best_i, ambiguous);
-                    best_d = L::sqrt(best_d2);
-                }
-            }
+            const T reach = U + rr[j];
+            const bool need = b < nb && !(dq2[j] > reach * reach);     // |q - c| - r <= U, root-free
+            lo = need && b < lo ? b : lo;
+            hi = need && b > hi ? b : hi;
         }
     }
+    if (hi < lo) { lo = 0; hi = nb - 1; }                                // nothing comparable: plain full scan
+    nearest_in_range<T, EXACT>(wp, lo * kWpBlock, min((hi + 1) * kWpBlock, wp.W), x, y, best_d2, best_i, ambiguous);
 }
 
 // stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
@@ -220,19 +235,33 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
     T px, py;
     wp.get(best_i, px, py);
     if (wp.seg != nullptr) {
-        // same sequential sum as the reference, eight precomputed segment lengths per trip:
-        // the reads go out together and the early exit becomes a per-lane predicate
+        // same sequential sum as the reference, eight precomputed segment lengths per trip.  The
+        // running total never decreases (lengths are >= 0), so a trip whose LAST partial sum is
+        // still short of the lookahead cannot contain the crossing: eight dependent adds and one
+        // compare, and only the trip that ends the walk is resolved entry by entry.
         bool done = total >= G.lookahead;
         for (int i0 = best_i + 1; i0 < wp.W && !done; i0 += 8) {
-            T sg[8];
+            T t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sg[k] = wp.seg_at(min(i0 + k, wp.W - 1));
+            for (int k = 0; k < 8; ++k) t[k] = wp.seg_at(min(i0 + k, wp.W - 1));
+            t[0] = total + t[0];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool take = !done && (i0 + k) < wp.W;
-                total = take ? total + sg[k] : total;
-                ce = take ? i0 + k : ce;
-                done = done || !take || total >= G.lookahead;
+            for (int k = 1; k < 8; ++k) t[k] = t[k - 1] + t[k];
+            const bool whole = i0 + 8 <= wp.W && t[7] < G.lookahead;      // NaN: false -> resolved below
+            if (__any(!whole)) {
+                if (!whole) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool take = !done && (i0 + k) < wp.W;
+                        total = take ? t[k] : total;
+                        ce = take ? i0 + k : ce;
+                        done = done || !take || total >= G.lookahead;
+                    }
+                }
+            }
+            if (whole) {
+                total = t[7];
+                ce = i0 + 7;
             }
         }
         wp.get(ce, px, py);
