@@ -102,6 +102,12 @@ def cpu_baseline(W, gpu_terminal=None):
     t0 = time.perf_counter()
     O.rollout(p, s0[:, :n1], tab, DT, path_id=pid[:n1], nthreads=1)
     t_one = time.perf_counter() - t0
+    # "what a NumPy user would get": the vectorised restatement (oracle/numpy_batch.py), all
+    # 65536 rollouts as arrays, 10 of the 200 steps (the reference itself cannot batch)
+    from oracle import numpy_batch as NB
+    t0 = time.perf_counter()
+    NB.rollout(NB.Params(), s0, tab[:, :10], DT, pid)
+    t_np = time.perf_counter() - t0
     err = None
     if gpu_terminal is not None:
         ref = np.asarray(ref[0] if isinstance(ref, tuple) else ref)
@@ -119,6 +125,8 @@ def cpu_baseline(W, gpu_terminal=None):
                   f"(65536 rollouts x {HORIZON} steps) on {threads} threads in {t_all:.2f} s, plus {n1} "
                   f"rollouts x {HORIZON} steps on 1 thread in {t_one:.2f} s",
         "value_1core": n1 * HORIZON / t_one,
+        "numpy_vectorised": {"value": N_PER_GPU * 10 / t_np, "unit": "vehicle-steps/s",
+                             "sample": f"65536 rollouts x 10 steps as NumPy arrays in {t_np:.2f} s (one process)"},
         "reference_python_1core": 4.04e3,  # NumPy reference, measured in the build container only
     }
 
@@ -228,6 +236,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rollouts_per_s": world * n_local * args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
+        # the same job without the exchange step (SURVEY 8d config 4 asks for both): kernel time only
+        "value_excluding_collective": world * n_local * HORIZON / kern_s,
         "config": {
             "workload": "BASELINE configs[2]: 65536 rollouts per GPU (ego r//7, lattice path r%7) x 200 "
                         "RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared via LDS; "

@@ -161,6 +161,23 @@ def test_g8_rollouts_cfg3_shared_controls(oracle, workloads):
     assert np.array_equal(term, term2)
 
 
+def test_vectorised_numpy_restatement_against_reference_vectors():
+    """oracle/numpy_batch.py (the "what a NumPy user would write" CPU line of bench.py) against
+    the reference's own outputs: G2 derivatives (random states, k = 12 inputs) and the G8
+    lattice rollouts (terminal states after 200 steps)."""
+    from oracle import numpy_batch as NB
+    p = NB.Params()
+    g = load_golden("g2_deriv.npz")
+    sd, axc, ayc = NB.planar_model(p, g["state"].T.copy(), g["torque"].T.copy(), g["mu"].T.copy(),
+                                   g["delta"].T.copy(), g["ax_ay_prev"][:, 0], g["ax_ay_prev"][:, 1])
+    scale = np.abs(g["state_dot"]).max(axis=1)
+    assert (np.abs(sd.T - g["state_dot"]).max(axis=1) <= 1e-11 * scale).all()
+    assert np.abs(np.stack([axc, ayc], axis=1) - g["acc"]).max() <= 1e-10
+    g = load_golden("g8_rollout_cfg3.npz")
+    term = NB.rollout(p, g["state0"].astype(np.float64), g["table"].astype(np.float64), float(g["dt"]), g["path_id"])
+    close(term, g["terminal"], 1e-9)
+
+
 def test_threads_do_not_change_results(oracle, workloads):
     p = oracle.default_params()
     s0, ctrl = workloads.config2(8, 30)
