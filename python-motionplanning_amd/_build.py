@@ -22,8 +22,9 @@ HEADERS = [os.path.join(CSRC, h) for h in ("vdyn_device.hpp", "vdyn_internal.hpp
           [os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-fast-math", "-Wall", "-Wno-unused-function",
-               # packed fp32 VALU issues at half rate on gfx950, so SLP-packing scalar
-               # fp32 math only adds v_mov shuffles: measured 5 % slower (profiles/README.md)
+               # the packed fp32 step is written by hand (csrc/vdyn_packed.hpp); the SLP vectoriser
+               # pairs unrelated scalars and pays more v_mov shuffles than it saves: measured
+               # 5 % slower on the scalar step (profiles/README.md)
                "-fno-slp-vectorize"]
 
 

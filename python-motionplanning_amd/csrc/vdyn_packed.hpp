@@ -2,15 +2,17 @@
 //
 // Why: at one wave per SIMD -- what 65536 rollouts give this chip -- throughput is bound by
 // how often ONE wave can issue, not by the ALUs: a lone wave issues one VALU instruction per
-// ~4.5 cycles whether it is v_fma_f32 or v_pk_fma_f32 (tools/ubench/issue_rate.hip: 5.4 vs 5.7
-// cycles at the 2.4 GHz nominal clock), so a packed instruction does two lanes' worth of work
-// in one issue slot.  (With 2+ waves per SIMD a packed op costs two scalar ops, i.e. nothing is
-// lost there either.)  The model pairs up naturally: (FL, FR) and (RL, RR) run the same tire
-// computation, and the ten states advance as five pairs.
+// ~4.6 cycles whether it is v_fma_f32 or v_pk_fma_f32 (tools/ubench/dep_latency.hip,
+// profiles/r01_ubench_dep_latency.txt), so a packed instruction does two lanes' worth of work in
+// one issue slot.  (With 2+ waves per SIMD a packed op costs 1.7 scalar ops: still a gain.)
+// The model pairs up naturally: (FL, FR) and (RL, RR) run the same tire computation, (sin, cos)
+// share a Horner chain, (U_dot, V_dot), (x_dot, y_dot), (axc, ayc) are 2-D rotations / cross
+// products, and the ten states advance as five pairs.
 //
-// What cannot be packed stays scalar on the halves of a pair: v_rcp / v_rsq, compares and
-// selects, min / max, |x|.  Polynomial coefficients live in VGPR pairs for the whole kernel
-// (VOP3P takes no literal constants on gfx9); PkConsts::init pins them there.
+// What cannot be packed stays scalar on the halves of a pair: v_rcp / v_rsq, min / max, |x|.
+// Compares and selects are avoided altogether (clamp indicator, pk_above_one).  Polynomial
+// coefficients live in VGPR pairs for the whole kernel (VOP3P takes no literal constants on
+// gfx9); PkConsts::init pins them there.
 //
 // Semantics are those of vdyn_device.hpp (same formulas, same quirk handling); only the order
 // of the four-tire sums differs ((FL+RL)+(FR+RR) instead of ((FL+FR)+RL)+RR).
