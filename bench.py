@@ -332,6 +332,23 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = timed_launches(run_cl, 3, torch)
     ex["closed_loop_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3,
                                        "controller_updates_per_s": n / 10 / t, "waypoints_per_table": 1024}
+    # the two variants with real HBM traffic: every step's state written out
+    # (48 B per vehicle-step) and the 45-column DataLog of Car.drive (180 B per vehicle-step)
+    Hd = 100
+    tabd_ = torch.from_numpy(tab).to(dev)
+    run_tr = lambda: vm.rollout(s0, tabd_, path_id=pid, traj_stride=1)
+    run_tr()
+    t = timed_launches(run_tr, 3, torch)
+    gb = n * 48 / t / 1e9
+    ex["trajectory_dump_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3, "hbm_GBs_algorithmic": gb,
+                                           "hbm_frac": gb / HBM_PEAK_GBS, "bytes_per_vehicle_step": 48}
+    run_dl = lambda: vm.closed_loop(cl[0], cl[1], cl[2], Hd, wcount=cl[3], path_id=cl[4], datalog=True)
+    run_dl()
+    t = timed_launches(run_dl, 3, torch)
+    gb = N_PER_GPU * Hd * 180 / t / 1e9
+    ex["closed_loop_datalog_65536x100_f32"] = {"steps_per_s": N_PER_GPU * Hd / t, "kernel_ms": t * 1e3,
+                                               "hbm_GBs_algorithmic": gb, "hbm_frac": gb / HBM_PEAK_GBS,
+                                               "bytes_per_vehicle_step": 180}
     del cl
     # BASELINE configs[0]: the reference's own call pattern -- ONE vehicle, one planar_model_RK4
     # call per sub-step through the reference-signature drop-in (host lists in, 9-value list out)
