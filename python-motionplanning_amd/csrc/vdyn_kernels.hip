@@ -560,7 +560,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     w.ss = w.bs = WPLDS ? 1 : Pn;
     w.W = min(max(wcount[pid], 1), Wmax);
     StepEngine<T> eng;
-    if (!DATALOG) eng.init(P);
+    eng.init(P);
 
     for (int t = 0; t < H; ++t) {
         if ((phase + t) % ctrl_every == 0) {   // wave-uniform test
@@ -571,7 +571,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
         T sd[10];
         Outputs18<T> o18;
-        if (DATALOG) rk4_advance<T, true, true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, &o18);
+        if (DATALOG) eng.template advance_diag<true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
         else eng.template advance<true, CS>(P, s, ax, ay, delta, tq, P.mu, h);
         if (DATALOG && active) {
             T *row = datalog + (int64_t)t * 45 * n + r;

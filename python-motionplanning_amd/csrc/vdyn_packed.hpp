@@ -206,9 +206,9 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
 template <bool REAR_STEERED, bool CS>
 __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], const f2 invB[2], const f2 C[2], f2 rw,
                                               f2 vxc, const f2 vyc[2], const f2 w[2], const f2 cd[2], const f2 sd[2],
-                                              const f2 muFz[2], f2 fx[2], f2 fy[2], f2 fxt[2], f2 fyt[2])
+                                              const f2 muFz[2], f2 fx[2], f2 fy[2], f2 fxt[2], f2 fyt[2], f2 s[2])
 {
-    f2 vx[2], vy[2], rvx[2], sx[2], sy[2], s2[2], rs[2], s[2], xs[2], ix[2], g[2], tmp[2];
+    f2 vx[2], vy[2], rvx[2], sx[2], sy[2], s2[2], rs[2], xs[2], ix[2], g[2], tmp[2];
     tmp[0] = vyc[0] * sd[0];
     vx[0] = fma2(vxc, cd[0], tmp[0]);
     tmp[0] = vxc * sd[0];
@@ -314,10 +314,17 @@ struct StepInv2 {
     f2 tqF, tqR;             // torque / Jw
 };
 
+// Diagnostics of one derivative evaluation as pairs (vehicle_model.py:420-423): chassis-frame
+// forces and combined slips of the front / rear pair, tire-frame forces of the front pair.
+struct Diag2 {
+    f2 fx[2], fy[2], s[2], fxt, fyt;
+};
+
 // vehicle_model.py:220-425 on pairs.  sc = (sin, cos) of the stage yaw.
-template <bool K2, bool CS>
+template <bool K2, bool CS, bool DIAG = false>
 __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
-                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, f2 &acc_c)
+                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, f2 &acc_c,
+                                              Diag2 *dg = nullptr)
 {
     const float U = s.uv.x, V = s.uv.y, wz = s.wy.x;
     const f2 U2 = f2{U, U}, V2 = f2{V, V}, wz2 = f2{wz, wz};
@@ -326,8 +333,14 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     const f2 Bq[2] = {Q.BF, Q.BR}, iBq[2] = {Q.invBF, Q.invBR}, Cq[2] = {Q.CF, Q.CR};
     const f2 vyq[2] = {f2{vyb.x, vyb.x}, f2{vyb.y, vyb.y}}, wq[2] = {s.wf, s.wr};
     const f2 cdq[2] = {c.cdF, c.cdR}, sdq[2] = {c.sdF, c.sdR}, mfq[2] = {c.muFzF, c.muFzR};
-    f2 fxq[2], fyq[2], fxtq[2], fytq[2];
-    tire_force2x2<!K2, CS>(K, Bq, iBq, Cq, Q.rw, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq);
+    f2 fxq[2], fyq[2], fxtq[2], fytq[2], slq[2];
+    tire_force2x2<!K2, CS>(K, Bq, iBq, Cq, Q.rw, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq, slq);
+    if (DIAG) {
+        dg->fx[0] = fxq[0]; dg->fx[1] = fxq[1];
+        dg->fy[0] = fyq[0]; dg->fy[1] = fyq[1];
+        dg->s[0] = slq[0]; dg->s[1] = slq[1];
+        dg->fxt = fxtq[0]; dg->fyt = fytq[0];
+    }
     const f2 fxF = fxq[0], fyF = fyq[0], fxtF = fxtq[0], fxR = fxq[1], fyR = fyq[1];
     // :376-378
     const f2 sfx = fxF + fxR, sfy = fyF + fyR;                 // (left sums, right sums)
@@ -346,10 +359,13 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
 }
 
 // FAST RK4 step (vehicle_model.py:427-445) on pairs; `ok` as in rk4_step.
-template <bool K2, bool CS>
+// DIAG: also state_dot (:440) and the 1-2-2-1 averaged outputs (:441).
+template <bool K2, bool CS, bool DIAG = false>
 __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
                                           const State5 &s, f2 axy, const float delta[4], const float tq[4],
-                                          const float mu[4], float h, State5 &sn, f2 &axy_n)
+                                          const float mu[4], float h, State5 &sn, f2 &axy_n,
+                                          State5 *state_dot = nullptr, Diag2 *outputs = nullptr, f2 *FzF_out = nullptr,
+                                          f2 *FzR_out = nullptr)
 {
     bool ok = true;
     StepInv2 c;
@@ -370,6 +386,7 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
         const f2 FzR = fma2(Q.dfyR, ay2, fma2(Q.dfxR, ax2, Q.Fz0R));
         c.muFzF = f2{mu[0], mu[1]} * FzF;
         c.muFzR = f2{mu[2], mu[3]} * FzR;
+        if (DIAG) { *FzF_out = FzF; *FzR_out = FzR; }
         c.tqF = f2{tq[0], tq[1]} * Q.inv_Jw;
         c.tqR = f2{tq[2], tq[3]} * Q.inv_Jw;
     }
@@ -381,27 +398,44 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
     State5 k, acc, st;
 
 #define VDYN_S5_EACH(OP) OP(uv) OP(wy) OP(wf) OP(wr) OP(xy)
-    planar_deriv2<K2, CS>(P, Q, K, c, s, sc0, k, a);                        // K1
+    Diag2 dg, dsum;
+#define VDYN_DG_EACH(OP) OP(fx[0]) OP(fx[1]) OP(fy[0]) OP(fy[1]) OP(s[0]) OP(s[1]) OP(fxt) OP(fyt)
+    planar_deriv2<K2, CS, DIAG>(P, Q, K, c, s, sc0, k, a, &dg);             // K1
     as2 = a;
+    if (DIAG) dsum = dg;
 #define VDYN_S5_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_1)
     sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a);                        // K2
+    planar_deriv2<K2, CS, DIAG>(P, Q, K, c, st, sc, k, a, &dg);             // K2
     as2 = fma2(two, a, as2);
+#define VDYN_DG_2(f) dsum.f = fma2(two, dg.f, dsum.f);
+    if (DIAG) { VDYN_DG_EACH(VDYN_DG_2) }
 #define VDYN_S5_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_2)
     sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a);                        // K3
+    planar_deriv2<K2, CS, DIAG>(P, Q, K, c, st, sc, k, a, &dg);             // K3
     as2 = fma2(two, a, as2);
+    if (DIAG) { VDYN_DG_EACH(VDYN_DG_2) }
 #define VDYN_S5_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
     VDYN_S5_EACH(VDYN_S5_3)
     sc = stage_sincos2(K, sc0, h * k.wy.y, ok);
-    planar_deriv2<K2, CS>(P, Q, K, c, st, sc, k, a);                        // K4
+    planar_deriv2<K2, CS, DIAG>(P, Q, K, c, st, sc, k, a, &dg);             // K4
     as2 = as2 + a;
     const float sixth = 1.0f / 6.0f;
     const f2 h6 = splat(h * sixth);
-#define VDYN_S5_4(f) sn.f = fma2(h6, acc.f + k.f, s.f);
+#define VDYN_S5_4(f) acc.f = acc.f + k.f; sn.f = fma2(h6, acc.f, s.f);
     VDYN_S5_EACH(VDYN_S5_4)
+    if (DIAG) {
+        const f2 sixth2 = splat(sixth);
+#define VDYN_S5_5(f) state_dot->f = acc.f * sixth2;
+        VDYN_S5_EACH(VDYN_S5_5)
+#undef VDYN_S5_5
+#define VDYN_DG_4(f) outputs->f = (dsum.f + dg.f) * sixth2;
+        VDYN_DG_EACH(VDYN_DG_4)
+#undef VDYN_DG_4
+    }
+#undef VDYN_DG_2
+#undef VDYN_DG_EACH
 #undef VDYN_S5_1
 #undef VDYN_S5_2
 #undef VDYN_S5_3
@@ -427,6 +461,13 @@ struct StepEngine {
                                             const T tq[4], const T mu[4], T h) const
     {
         rk4_advance<T, K2, false, CS>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr);
+    }
+    // the same step with state_dot [10] and the averaged outputs [18] (vehicle_model.py:440-441)
+    template <bool K2, bool CS>
+    __device__ __forceinline__ void advance_diag(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
+                                                 const T tq[4], const T mu[4], T h, T sd[10], Outputs18<T> &o) const
+    {
+        rk4_advance<T, K2, true, CS>(P, s, ax, ay, delta, tq, mu, h, sd, &o);
     }
 };
 
@@ -470,6 +511,40 @@ struct StepEngine<float> {
         s[0] = Sn.uv.x; s[1] = Sn.uv.y; s[2] = Sn.wy.x; s[7] = Sn.wy.y;
         s[3] = Sn.wf.x; s[4] = Sn.wf.y; s[5] = Sn.wr.x; s[6] = Sn.wr.y;
         s[8] = Sn.xy.x; s[9] = Sn.xy.y;
+        ax = axn;
+        ay = ayn;
+    }
+    template <bool K2, bool CS>
+    __device__ __forceinline__ void advance_diag(const DevParams<float> &P, float s[10], float &ax, float &ay,
+                                                 const float delta[4], const float tq[4], const float mu[4],
+                                                 float h, float sd[10], Outputs18<float> &o) const
+    {
+        State5 S, Sn, D;
+        S.uv = f2{s[0], s[1]};
+        S.wy = f2{s[2], s[7]};
+        S.wf = f2{s[3], s[4]};
+        S.wr = f2{s[5], s[6]};
+        S.xy = f2{s[8], s[9]};
+        Diag2 g;
+        f2 axy_n, FzF, FzR;
+        const bool ok = rk4_step2<K2, CS, true>(P, Q, K, S, f2{ax, ay}, delta, tq, mu, h, Sn, axy_n, &D, &g, &FzF, &FzR);
+        float sn[10], axn = axy_n.x, ayn = axy_n.y;
+        sn[0] = Sn.uv.x; sn[1] = Sn.uv.y; sn[2] = Sn.wy.x; sn[7] = Sn.wy.y;
+        sn[3] = Sn.wf.x; sn[4] = Sn.wf.y; sn[5] = Sn.wr.x; sn[6] = Sn.wr.y;
+        sn[8] = Sn.xy.x; sn[9] = Sn.xy.y;
+        sd[0] = D.uv.x; sd[1] = D.uv.y; sd[2] = D.wy.x; sd[7] = D.wy.y;
+        sd[3] = D.wf.x; sd[4] = D.wf.y; sd[5] = D.wr.x; sd[6] = D.wr.y;
+        sd[8] = D.xy.x; sd[9] = D.xy.y;
+        o.v[0] = g.fx[0].x; o.v[1] = g.fx[0].y; o.v[2] = g.fx[1].x; o.v[3] = g.fx[1].y;        // :420-423
+        o.v[4] = g.fy[0].x; o.v[5] = g.fy[0].y; o.v[6] = g.fy[1].x; o.v[7] = g.fy[1].y;
+        o.v[8] = FzF.x; o.v[9] = FzF.y; o.v[10] = FzR.x; o.v[11] = FzR.y;
+        o.v[12] = g.s[0].x; o.v[13] = g.s[0].y; o.v[14] = g.s[1].x; o.v[15] = g.s[1].y;
+        o.v[16] = g.fxt.x; o.v[17] = g.fyt.x;
+        if (__builtin_expect(__any(!ok) != 0, 0)) {
+            if (!ok) rk4_step<float, K2, true, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, sd, &o);
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s[i] = sn[i];
         ax = axn;
         ay = ayn;
     }
