@@ -40,8 +40,11 @@ VALU_PEAK_TFLOPS = 157.3                        # fp32 vector peak (= fp32 MFMA 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+                    help="untimed load before the W warm-up steps: an idle MI355X needs ~50-100 ms of work to "
+                         "reach its sustained clock (the first launches after idle run ~15 %% slower); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations")
     ap.add_argument("--strong", action="store_true",
@@ -210,6 +213,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp (reported in the JSON as `prewarm`): the same step, untimed, for a fixed wall time
+    prewarm_launches = 0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(16):
+            step(False)
+        prewarm_launches += 16
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -236,6 +247,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rollouts_per_s": world * n_local * args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
+        "prewarm": {"ms": args.prewarm_ms, "launches": prewarm_launches,
+                    "why": "GPU clock ramp after idle, before the W untimed warm-up steps"},
         # the same job without the exchange step (SURVEY 8d config 4 asks for both): kernel time only
         "value_excluding_collective": world * n_local * HORIZON / kern_s,
         "config": {
