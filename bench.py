@@ -58,15 +58,22 @@ def parse():
     return ap.parse_args()
 
 
-def timed_launches(fn, n, torch):
-    """Average duration (s) of n launches of fn(), HIP events on the launching stream."""
+def timed_launches(fn, n, torch, warm_ms=40.0):
+    """Median duration (s) of n launches of fn(), HIP events on the launching stream, after
+    `warm_ms` of the same launches untimed (the host-side set-up between the secondary
+    configurations leaves the GPU idle long enough for its clock to drop)."""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < warm_ms:
+        fn()
+        torch.cuda.synchronize()
+    n = max(n, 5)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:
         a.record()
         fn()
         b.record()
     torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+    return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
 
 def usable_cores():
