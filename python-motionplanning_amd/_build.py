@@ -25,7 +25,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # the packed fp32 step is written by hand (csrc/vdyn_packed.hpp); the SLP vectoriser
                # pairs unrelated scalars and pays more v_mov shuffles than it saves: measured
                # 5 % slower on the scalar step (profiles/README.md)
-               "-fno-slp-vectorize"]
+               "-fno-slp-vectorize",
+               # one wave per SIMD is the operating point: schedule for instruction-level parallelism,
+               # not for occupancy (A/B at the sustained clock: headline -1.7 %, fp64 -3.5 %)
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def hipcc_path():

@@ -90,29 +90,28 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             }
             __syncthreads();
         }
-        // (two steps per trip, to save the ten v_mov that carry the state around the SAFE-redo
-        // branch, was measured: no gain, 0.3068 vs 0.3054 ms)
-        // Controls read from global memory (per-rollout, or a table too wide for LDS): step t + 1's are
-        // fetched before step t is integrated, so that their latency hides behind a whole RK4 step
-        // instead of stalling the lone wave at its top (measured -5 %).  LDS-staged tables are read in
-        // place: their latency is short and the extra copies cost more than they hide (+2.5 %).
+        // Step t + 1's controls are fetched before step t is integrated, so that their latency (LDS
+        // or memory) hides behind a whole RK4 step instead of stalling the lone wave at its top:
+        // -4.4 % with the table in LDS, -5 % with per-rollout controls in global memory (A/B at the
+        // sustained clock, three runs each, +-0.2 %).
         auto fetch = [&](Ctrl<T, K> &c, int tc) __attribute__((always_inline)) {
             const int t = t0 + tc;
             if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
         };
+        // (Two steps per trip with the control sets ping-ponging -- no copies, state advanced in
+        // place -- was measured at the sustained clock: 0.2404 ms against 0.2376 ms for this loop.)
         Ctrl<T, K> c;
-        if (LAYOUT != 1) fetch(c, 0);
+        fetch(c, 0);
         for (int tc = 0; tc < tc_n; ++tc) {
             const int t = t0 + tc;
             Ctrl<T, K> cn;
-            if (LAYOUT != 1) fetch(cn, min(tc + 1, tc_n - 1));
-            else fetch(c, tc);
+            fetch(cn, min(tc + 1, tc_n - 1));
 
             if (DIAG) rk4_advance<T, K == 2, true, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
             else eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
-            if (LAYOUT != 1) c = cn;
+            c = cn;
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
@@ -195,13 +194,20 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
             }
             __syncthreads();
         }
-        for (int tc = 0; tc < tc_n; ++tc) {
+        auto fetch = [&](Ctrl<T, K> &c, int tc) __attribute__((always_inline)) {
             const int t = t0 + tc;
-            Ctrl<T, K> c;
             if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
+        };
+        Ctrl<T, K> c;
+        fetch(c, 0);
+        for (int tc = 0; tc < tc_n; ++tc) {
+            const int t = t0 + tc;
+            Ctrl<T, K> cn;
+            fetch(cn, min(tc + 1, tc_n - 1));          // behind this step (see rollout_kernel)
             eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
+            c = cn;
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
 #pragma unroll
@@ -376,11 +382,14 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         T s[10], ax = ax0, ay = ay0, dsum = T(0);
 #pragma unroll
         for (int i = 0; i < 10; ++i) s[i] = s0[i];
+        Ctrl<T, 2> cc;                         // step t + 1's controls are fetched behind step t (see rollout_kernel)
+        if (H > 0) cc.set(P, cand + c, C);
         for (int t = 0; t < H; ++t) {
-            Ctrl<T, 2> cc;
-            cc.set(P, cand + ((int64_t)t * 2) * C + c, C);
+            Ctrl<T, 2> cn;
+            cn.set(P, cand + ((int64_t)min(t + 1, H - 1) * 2) * C + c, C);
             eng.template advance<true, CS>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h);
             dsum += cc.delta[0] * cc.delta[0];
+            cc = cn;
         }
         const T dx = s[8] - gx, dy = s[9] - gy;
         const T cost = sqrt_t(dx * dx + dy * dy) + w_delta * dsum;
