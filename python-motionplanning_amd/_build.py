@@ -15,20 +15,23 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # VDYN_LIB_PATH: load/build an alternative in-tree build (A/B experiments only)
 LIB_PATH = os.environ.get("VDYN_LIB_PATH") or os.path.join(PKG_DIR, "libvdyn_hip.so")
-SOURCES = ["vdyn_kernels.hip", "vdyn_capi.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("vdyn_device.hpp", "vdyn_internal.hpp", "vdyn_fastmath.hpp",
-                                           "vdyn_packed.hpp", "vdyn_controls.hpp", "vdyn_quad.hpp",
-                                           "vdyn_lattice.hpp")] + \
+# One wave per SIMD is the operating point of these kernels: schedule for instruction-level
+# parallelism, not for occupancy.  A/B at the sustained clock (three runs each, +-0.2 %): the fp32
+# kernels are fastest under max-ilp (headline -1.7 % against the default strategy), the fp64 ones
+# under iterative-ilp (configs[1] 1.02 -> 0.86 ms) -- hence one translation unit per precision.
+SOURCES = [("vdyn_kernels_f32.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+           ("vdyn_kernels_f64.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
+           ("vdyn_capi.hip", [])]
+HEADERS = [os.path.join(CSRC, h) for h in ("vdyn_kernels.hip", "vdyn_device.hpp", "vdyn_internal.hpp",
+                                           "vdyn_fastmath.hpp", "vdyn_packed.hpp", "vdyn_controls.hpp",
+                                           "vdyn_quad.hpp", "vdyn_lattice.hpp")] + \
           [os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-fno-fast-math", "-Wall", "-Wno-unused-function",
                # the packed fp32 step is written by hand (csrc/vdyn_packed.hpp); the SLP vectoriser
                # pairs unrelated scalars and pays more v_mov shuffles than it saves: measured
                # 5 % slower on the scalar step (profiles/README.md)
-               "-fno-slp-vectorize",
-               # one wave per SIMD is the operating point: schedule for instruction-level parallelism,
-               # not for occupancy (A/B at the sustained clock: headline -1.7 %, fp64 -3.5 %)
-               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+               "-fno-slp-vectorize"]
 
 
 def hipcc_path():
@@ -42,21 +45,39 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source of the package into libvdyn_hip.so."""
+    """Compile every HIP source of the package (in parallel, one object each) and link
+    libvdyn_hip.so."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", LIB_PATH + ".tmp",
-           *[os.path.join(CSRC, s) for s in SOURCES]]
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = hipcc_path()
+    objdir = os.path.join(PKG_DIR, "build", os.path.basename(LIB_PATH) + ".d")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(item):
+        src, flags = item
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *HIPCC_FLAGS, *flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

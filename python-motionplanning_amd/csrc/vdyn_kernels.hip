@@ -1255,7 +1255,13 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     template hipError_t launch_plan_lattice<T>(const LatticeArgs<T> &, hipStream_t);                 \
     template hipError_t launch_interpolate_waypoints<T>(int, int, int, const T *, const int *, double, int, T *, \
                                                         int *, hipStream_t);
+// One translation unit per precision (vdyn_kernels_f32.hip / _f64.hip include this file): they
+// compile in parallel and with the instruction-scheduling strategy that suits each (_build.py).
+#if !defined(VDYN_ONLY_F64)
 VDYN_INSTANTIATE(float)
+#endif
+#if !defined(VDYN_ONLY_F32)
 VDYN_INSTANTIATE(double)
+#endif
 
 }  // namespace vdyn
