@@ -99,7 +99,7 @@ const char *vdyn_last_error(const VdynHandle *h);
  *   4            wheel-parallel, four lanes per rollout: 2-3x shorter serial chain, meant for
  *                small N where the chip is mostly empty; agrees with 1 to rounding
  *                (different summation order of the four tire forces), not bit for bit;
- *   0            automatic: 4 when N <= 32768 (fp32) / 49152 (fp64), else 1.               */
+ *   0            automatic: 4 when N <= 16384 (fp32) / 32768 (fp64), else 1.               */
 enum { VDYN_OPT_LANES_PER_ROLLOUT = 1 };
 int vdyn_set_option(VdynHandle *h, int option, int value);
 /* hipStreamSynchronize(stream) for callers that have no HIP binding of their own. */

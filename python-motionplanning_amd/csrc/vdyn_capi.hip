@@ -225,9 +225,10 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     if (a.traj && a.traj_stride <= 0) return h->fail(VDYN_ERR_ARG, w + ": traj needs traj_stride > 0");
     VDYN_HIP(h, hipSetDevice(h->device));
     vdyn::RolloutArgs<T> b = a;
-    // 0 = automatic: wheel-parallel while it is measurably faster (tools/sweep_lanes.py: fp32
-    // 2.0x up to 16384 rollouts, 1.15x at 32768, 0.8x beyond; fp64 2.9x .. 1.2x at 49152)
-    const int64_t auto_max = sizeof(T) == 4 ? 32768 : 49152;
+    // 0 = automatic: wheel-parallel while it is measurably faster (tools/sweep_lanes.py at the
+    // sustained clock, against the packed lane kernel: fp32 1.35x up to 16384 rollouts, 0.8x at
+    // 24576; fp64 2.3x up to 16384, 1.46x at 32768, 1.0x at 40960)
+    const int64_t auto_max = sizeof(T) == 4 ? 16384 : 32768;
     b.lanes_per_rollout = h->lanes_per_rollout == 0 ? (a.n <= auto_max ? 4 : 1) : h->lanes_per_rollout;
     VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, b, (hipStream_t)stream));
     return VDYN_OK;

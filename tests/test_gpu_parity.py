@@ -596,7 +596,7 @@ def test_wheel_parallel_kernel_matches_oracle_and_lane_kernel(pkg, oracle, workl
     c = np.concatenate([g["delta"], g["torque"], g["mu"]], axis=1).T
     term = vm(dt, 4).rollout(g["state0"].T.copy(), np.broadcast_to(c[None], (H, 12, c.shape[1])).copy())
     assert parity(term, g["terminal"].T, F64_TOL) <= 1e-8
-    # automatic mode: wheel-parallel for small batches, the lane kernel above 32768 (fp32)
+    # automatic mode: wheel-parallel for small batches, the lane kernel above 16384 (fp32) / 32768 (fp64)
     auto = vm(1e-3, 0)
     assert np.array_equal(auto.rollout(s0, ctrl), q)
     big0, btab, bpid = workloads.config3(40000, 20)

@@ -14,8 +14,12 @@ W = pkg.workloads
 dev = torch.device("cuda:0")
 
 
-def timed(fn, n=5):
-    fn()
+def timed(fn, n=7):
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.05:          # clock warm
+        fn()
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:
         a.record(); fn(); b.record()
