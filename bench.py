@@ -225,8 +225,8 @@ def main():
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
         for _ in range(16):
-            step(False)
-        prewarm_launches += 16
+            vm.rollout(s0, tabd, path_id=pid)     # kernel only: a wall-time loop must not contain a collective
+        prewarm_launches += 16                     # (ranks would issue different numbers of them)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
