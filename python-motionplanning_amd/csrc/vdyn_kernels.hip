@@ -44,6 +44,20 @@ struct Ctrl {
     }
 };
 
+// Stage steps [t0, t0 + tc_n) of the shared control table ctrl [P][H][K] into LDS as tab [tc][k][p]:
+// one path's slice is contiguous in memory, so the lanes read along it (coalesced, no runtime
+// division) and scatter into LDS with stride P (7 for the lattice: conflict-free).
+template <typename T, int K>
+__device__ __forceinline__ void stage_control_table(T *__restrict__ tab, const T *__restrict__ ctrl, int Pn, int H,
+                                                    int t0, int tc_n)
+{
+    const int row = tc_n * K;
+    for (int p = 0; p < Pn; ++p) {
+        const T *src = ctrl + ((int64_t)p * H + t0) * K;
+        for (int j = threadIdx.x; j < row; j += kBlock) tab[j * Pn + p] = src[j];   // j = tc * K + kk
+    }
+}
+
 // H zero-order-hold RK4 steps per lane (the loop of drive.py:114,141-143 with
 // vehicle_model.py:427-445 inside).  DIAG additionally returns the last step's
 // state_dot / outputs (used for H = 1: the planar_model_RK4 drop-in).
@@ -81,13 +95,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
             __syncthreads();  // previous chunk fully consumed
-            const int total = tc_n * K * Pn;
-            for (int idx = threadIdx.x; idx < total; idx += kBlock) {
-                const int p = idx % Pn;
-                const int kk = (idx / Pn) % K;
-                const int tc = idx / (Pn * K);
-                tab[idx] = ctrl[((int64_t)p * H + (t0 + tc)) * K + kk];
-            }
+            stage_control_table<T, K>(tab, ctrl, Pn, H, t0, tc_n);
             __syncthreads();
         }
         // Step t + 1's controls are fetched before step t is integrated, so that their latency (LDS
@@ -185,13 +193,7 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
             __syncthreads();
-            const int total = tc_n * K * Pn;
-            for (int idx = threadIdx.x; idx < total; idx += kBlock) {
-                const int p = idx % Pn;
-                const int kk = (idx / Pn) % K;
-                const int tc = idx / (Pn * K);
-                tab[idx] = ctrl[((int64_t)p * H + (t0 + tc)) * K + kk];
-            }
+            stage_control_table<T, K>(tab, ctrl, Pn, H, t0, tc_n);
             __syncthreads();
         }
         auto fetch = [&](Ctrl<T, K> &c, int tc) __attribute__((always_inline)) {
@@ -260,13 +262,7 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
             __syncthreads();
-            const int total = tc_n * K * Pn;
-            for (int idx = threadIdx.x; idx < total; idx += kBlock) {
-                const int p = idx % Pn;
-                const int kk = (idx / Pn) % K;
-                const int tc = idx / (Pn * K);
-                tab[idx] = ctrl[((int64_t)p * H + (t0 + tc)) * K + kk];
-            }
+            stage_control_table<T, K>(tab, ctrl, Pn, H, t0, tc_n);
             __syncthreads();
         }
         for (int tc = 0; tc < tc_n; ++tc) {
