@@ -511,7 +511,8 @@ int closed_loop_dev(VdynHandle *h, const VdynCtrlGains *g, const vdyn::ClosedLoo
         if (h->d_aux) { (void)hipFree(h->d_aux); h->d_aux = nullptr; h->d_aux_bytes = 0; }
         if (hipMalloc(&h->d_aux, aux_bytes) != hipSuccess) {
             (void)hipGetLastError();
-            h->d_aux = nullptr;               // no room: the kernels fall back to the plain full scan
+            h->d_aux = nullptr;
+            return h->fail(VDYN_ERR_OOM, std::string(who) + ": auxiliary waypoint tables do not fit");
         } else {
             h->d_aux_bytes = aux_bytes;
         }

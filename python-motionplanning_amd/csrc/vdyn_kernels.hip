@@ -422,13 +422,19 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
 constexpr int kAuxTP = 32;                 // tables per tile
 constexpr int kAuxTJ = 2 * kWpBlock;       // waypoints per tile = two bounding circles per table
 
-template <typename T>
+//   LDSIMG = false: seg [j][P], bnd [b][4][P]               (transposed, read in place by the lanes)
+//   LDSIMG = true:  seg [P][Wmax + 1], bnd [P][nb][4]         (the closed loop's LDS image: every
+//                   workgroup copies it instead of recomputing it 256 times over)
+template <typename T, bool LDSIMG>
 __global__ void __launch_bounds__(kBlock)
 waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ wcount, int Pn, T *__restrict__ aux)
 {
     __shared__ T tx[kAuxTP][kAuxTJ + 2], ty[kAuxTP][kAuxTJ + 2];   // column 0 = the waypoint before the tile
     const int nb = (Wmax + kWpBlock - 1) / kWpBlock;
-    T *seg = aux, *bnd = aux + (int64_t)Wmax * Pn;
+    const int64_t seg_len = LDSIMG ? (int64_t)(Wmax + 1) * Pn : (int64_t)Wmax * Pn;
+    T *seg = aux, *bnd = aux + seg_len;
+    const int64_t ss_j = LDSIMG ? 1 : Pn, ss_p = LDSIMG ? Wmax + 1 : 1;         // seg[j * ss_j + p * ss_p]
+    const int64_t bs = LDSIMG ? 1 : Pn, bp = LDSIMG ? (int64_t)nb * 4 : 1;       // bnd[(4 b + c) * bs + p * bp]
     const int tiles_j = (Wmax + kAuxTJ - 1) / kAuxTJ;
     const int p0 = (blockIdx.x / tiles_j) * kAuxTP, j0 = (blockIdx.x % tiles_j) * kAuxTJ;
     // read: thread -> (table row, waypoint) with the waypoint fastest
@@ -450,7 +456,7 @@ waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ 
         const int jj = i / kAuxTP, pp = i - jj * kAuxTP;
         const int p = p0 + pp, j = j0 + jj;
         if (p < Pn && j < Wmax)
-            seg[(int64_t)j * Pn + p] = j == 0 ? T(0) : segment_length<T>(tx[pp][jj], ty[pp][jj], tx[pp][jj + 1], ty[pp][jj + 1]);
+            seg[j * ss_j + p * ss_p] = j == 0 ? T(0) : segment_length<T>(tx[pp][jj], ty[pp][jj], tx[pp][jj + 1], ty[pp][jj + 1]);
     }
     // bounding circles: one thread per (table, block of 32 waypoints) of the tile
     if (threadIdx.x < kAuxTP * (kAuxTJ / kWpBlock)) {
@@ -473,19 +479,20 @@ waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ 
                 r2 = d2 > r2 ? d2 : r2;
             }
             const bool empty = lo >= hi;                                   // a block past the table's end: never entered
-            bnd[((int64_t)4 * b + 0) * Pn + p] = empty ? T(0) : cx;
-            bnd[((int64_t)4 * b + 1) * Pn + p] = empty ? T(0) : cy;
-            bnd[((int64_t)4 * b + 2) * Pn + p] = empty ? T(0) : Lib<T>::sqrt(r2) * T(1.00001) + T(1e-30);
-            bnd[((int64_t)4 * b + 3) * Pn + p] = T(0);
+            T *o = bnd + (int64_t)4 * b * bs + p * bp;
+            o[0] = empty ? T(0) : cx;
+            o[bs] = empty ? T(0) : cy;
+            o[2 * bs] = empty ? T(0) : Lib<T>::sqrt(r2) * T(1.00001) + T(1e-30);     // never smaller than the true radius
+            o[3 * bs] = T(0);
         }
     }
 }
 
 template <typename T>
-size_t waypoint_aux_len(int P, int Wmax)
+size_t waypoint_aux_len(int P, int Wmax, bool ldsimg)
 {
     const size_t nb = (size_t)(Wmax + kWpBlock - 1) / kWpBlock;
-    return (size_t)Wmax * P + nb * 4 * P;
+    return (size_t)(Wmax + (ldsimg ? 1 : 0)) * P + nb * 4 * P;
 }
 
 // Closed-loop rollout: the sub-step loop of drive.py:114-151 without the planner.  Every
@@ -516,37 +523,16 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     T *lds_seg = lds_wp + (int64_t)Pn * wstride * 2;
     T *lds_bnd = lds_seg + (int64_t)Pn * wstride;      // [P][nbmax][4] bounding circles of 32-waypoint blocks
     if (WPLDS) {
-        for (int i = threadIdx.x; i < Pn * Wmax; i += kBlock) {
-            const int p = i / Wmax, j = i - p * Wmax;
-            const T wx = wp[2 * (int64_t)i], wy = wp[2 * (int64_t)i + 1];
-            lds_wp[2 * (p * wstride + j)] = wx;
-            lds_wp[2 * (p * wstride + j) + 1] = wy;
-            // segment lengths, once per workgroup instead of once per lane per walk step
-            lds_seg[p * wstride + j] = j == 0 ? T(0) : segment_length<T>(wp[2 * (int64_t)i - 2], wp[2 * (int64_t)i - 1], wx, wy);
+        // (x, y) pairs row by row (the LDS rows are one entry longer than the table's), then the
+        // segment lengths and bounding circles, which waypoint_aux_kernel<T, true> computed once for
+        // all workgroups in exactly this layout: two flat copies
+        for (int p = 0; p < Pn; ++p) {
+            const T *src = wp + (int64_t)p * Wmax * 2;
+            T *dst = lds_wp + (int64_t)p * wstride * 2;
+            for (int j = threadIdx.x; j < 2 * Wmax; j += kBlock) dst[j] = src[j];
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < Pn * nbmax; i += kBlock) {
-            const int p = i / nbmax, b = i - p * nbmax;
-            const int W = min(max(wcount[p], 1), Wmax);
-            const int lo = b * kWpBlock, hi = min(lo + kWpBlock, W);
-            T x0 = T(INFINITY), x1 = -T(INFINITY), y0 = T(INFINITY), y1 = -T(INFINITY);
-            for (int j = lo; j < hi; ++j) {
-                const T wx = lds_wp[2 * (p * wstride + j)], wy = lds_wp[2 * (p * wstride + j) + 1];
-                x0 = wx < x0 ? wx : x0; x1 = wx > x1 ? wx : x1;
-                y0 = wy < y0 ? wy : y0; y1 = wy > y1 ? wy : y1;
-            }
-            const T cx = T(0.5) * (x0 + x1), cy = T(0.5) * (y0 + y1);
-            T r2 = T(0);
-            for (int j = lo; j < hi; ++j) {
-                const T dx = lds_wp[2 * (p * wstride + j)] - cx, dy = lds_wp[2 * (p * wstride + j) + 1] - cy;
-                const T d2 = dx * dx + dy * dy;
-                r2 = d2 > r2 ? d2 : r2;
-            }
-            T *o = lds_bnd + 4 * (int64_t)i;
-            o[0] = cx; o[1] = cy;
-            o[2] = Lib<T>::sqrt(r2) * T(1.00001) + T(1e-30);     // never smaller than the true radius
-            o[3] = T(0);
-        }
+        const int naux = Pn * wstride + Pn * nbmax * 4;          // lds_seg and lds_bnd are adjacent
+        for (int i = threadIdx.x; i < naux; i += kBlock) lds_seg[i] = aux[i];
         __syncthreads();
     }
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -571,7 +557,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     const int pid = min(max(path_id[r], 0), Pn - 1);
     Waypoints<T> w;
     w.base = WPLDS ? lds_wp + (int64_t)pid * wstride * 2 : wp + (int64_t)pid * Wmax * 2;
-    // not in LDS: the transposed global tables of waypoint_aux_kernel (nullptr: plain full scan)
+    // not in LDS: the transposed global tables of waypoint_aux_kernel<T, false> (nullptr: plain full scan)
     w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : (aux != nullptr ? aux + pid : nullptr);
     w.bounds = WPLDS ? lds_bnd + (int64_t)pid * nbmax * 4 : (aux != nullptr ? aux + (int64_t)Wmax * Pn + pid : nullptr);
     w.ss = w.bs = WPLDS ? 1 : Pn;
@@ -579,11 +565,14 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     StepEngine<T> eng;
     eng.init(P);
 
+    int until_update = (ctrl_every - phase % ctrl_every) % ctrl_every;   // steps until (phase + t) % ctrl_every == 0
     for (int t = 0; t < H; ++t) {
-        if ((phase + t) % ctrl_every == 0) {   // wave-uniform test
+        if (until_update == 0) {               // wave-uniform; a countdown instead of a modulo per step
             T steer_raw;
             controller_update<T>(G, w, s, h, c, steer_raw);
+            until_update = ctrl_every;
         }
+        --until_update;
         const T delta[4] = {c.delta, c.delta, T(0), T(0)};
         const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
         T sd[10];
@@ -1130,10 +1119,15 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
     const bool lds = wp_bytes <= kClosedLoopLdsBudget;
     const bool cs = shape_factors_small(p);
-    if (!lds && a.aux != nullptr) {
+    if (a.aux == nullptr && lds) return hipErrorInvalidValue;       // the LDS image is not optional
+    if (a.aux != nullptr) {
         const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
-        hipLaunchKernelGGL((waypoint_aux_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
-                           a.wcount, a.P, a.aux);
+        if (lds)
+            hipLaunchKernelGGL((waypoint_aux_kernel<T, true>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp,
+                               a.Wmax, a.wcount, a.P, a.aux);
+        else
+            hipLaunchKernelGGL((waypoint_aux_kernel<T, false>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp,
+                               a.Wmax, a.wcount, a.P, a.aux);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
     }
@@ -1148,7 +1142,7 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
         hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV>), dim3(grid), dim3(kBlock),         \
                            LDSV ? wp_bytes : 0, st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0,  \
                            a.cstate0, a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.terminal,    \
-                           a.cstate, a.log, a.datalog, LDSV ? (const T *)nullptr : (const T *)a.aux); \
+                           a.cstate, a.log, a.datalog, (const T *)a.aux);                             \
     }
 #define VDYN_CL(CSV, LDSV)                                                                            \
     if (a.datalog != nullptr) VDYN_CL2(CSV, LDSV, true) else VDYN_CL2(CSV, LDSV, false)
@@ -1161,16 +1155,15 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     return hipGetLastError();
 }
 
-// Bytes of device scratch the controllers want for (P tables x Wmax waypoints): 0 when the closed
-// loop stages the tables in LDS; the single controller update has no LDS stage and asks for it
-// once the plain full scan would be the slower choice.
+// Bytes of device scratch the controllers need for (P tables x Wmax waypoints): the closed loop's
+// LDS image or, for tables too large for LDS, the transposed global tables; the single controller
+// update has no LDS stage and asks for the latter once the plain full scan would be slower.
 template <typename T>
 size_t closed_loop_aux_bytes(int P, int Wmax, bool update_only)
 {
     const size_t wp_bytes = ((size_t)P * (Wmax + 1) * 3 + (size_t)P * ((Wmax + kWpBlock - 1) / kWpBlock) * 4) * sizeof(T);
-    if (!update_only && wp_bytes <= kClosedLoopLdsBudget) return 0;
-    if (update_only && Wmax < 4 * kWpBlock) return 0;
-    return waypoint_aux_len<T>(P, Wmax) * sizeof(T);
+    if (update_only) return Wmax < 4 * kWpBlock ? 0 : waypoint_aux_len<T>(P, Wmax, false) * sizeof(T);
+    return waypoint_aux_len<T>(P, Wmax, wp_bytes <= kClosedLoopLdsBudget) * sizeof(T);
 }
 
 template <typename T>
@@ -1181,7 +1174,7 @@ hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
     if (a.aux != nullptr) {
         const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
-        hipLaunchKernelGGL((waypoint_aux_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
+        hipLaunchKernelGGL((waypoint_aux_kernel<T, false>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
                            a.wcount, a.P, a.aux);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;

@@ -11,12 +11,15 @@ def run(tag, **kw):
     g = pkg._lib.default_ctrl_gains()
     for k, v in kw.pop("gains", {}).items(): setattr(g, k, v)
     f = lambda: vm.closed_loop(s0, c0, wp, 200, wcount=wc, path_id=pid, gains=g, **kw)
-    f(); torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.06:
+        f(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(5): f()
+    for _ in range(10): f()
     b.record(); torch.cuda.synchronize()
-    print(f"{tag:40s} {a.elapsed_time(b)/5:.3f} ms")
+    print(f"{tag:40s} {a.elapsed_time(b)/10:.3f} ms")
 run("default (20 updates)")
 run("lookahead = 0 (no walk)", gains={"lookahead": 0.0})
 run("ctrl_every = 100 (2 updates)", ctrl_every=100)
