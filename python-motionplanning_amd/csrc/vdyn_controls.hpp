@@ -179,9 +179,9 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, 
             T cx, cy, r;
             wp.bound(min(b0 + j, nb - 1), cx, cy, r);
             const T ex = cx - x, ey = cy - y;
-            // float root, inflated: an upper bound does not need the last bits
+            // v_sqrt_f32 (1 ulp, no denormal fix-up), inflated: an upper bound does not need the last bits
             // (+1e-18: distances below the float range's root would otherwise round to zero)
-            ub[j] = (T)__builtin_sqrtf((float)(ex * ex + ey * ey)) * T(1.000001) + r + T(1e-18);
+            ub[j] = (T)__builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey)) * T(1.000001) + r + T(1e-18);
         }
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) U = ub[j] < U ? ub[j] : U;     // NaN never lowers U
