@@ -447,6 +447,47 @@ def test_closed_loop_batch_vs_oracle_and_properties(gpu_vm, pkg, oracle):
     assert np.array_equal(out[1], log[0, 14]) and np.array_equal(cu[4], log[0, 12])
 
 
+def test_closed_loop_private_tables_global_path(gpu_vm, pkg, oracle):
+    """One waypoint table per vehicle (100 tables of up to 2100 points: far beyond LDS), ragged
+    counts, table count and length that are no multiples of the aux kernel's 32 x 64 tiles: the
+    transposed segment-length / bounding-circle tables in global memory, against the oracle
+    (target indices exact) in fp64, and fp32 within tolerance."""
+    g = load_golden("g9_closed_loop_controls.npz")
+    dt = 1e-3
+    vm = gpu_vm(dt)
+    gains = _g9_gains(pkg, g)
+    cp = oracle.ctrl_params(*g["gains"])
+    rng = np.random.default_rng(17)
+    n = P = 100
+    Wmax = 2100
+    wc = rng.integers(300, Wmax + 1, P).astype(np.int32)
+    wc[:3] = [Wmax, 33, 64]
+    base = g["waypoints"][0, 300:300 + Wmax, :2]                        # 1 cm spacing, 21 m of the reference's path
+    wp = np.zeros((P, Wmax, 2))
+    off = rng.normal(0, 0.3, (P, 2))
+    for p in range(P):
+        wp[p, :wc[p]] = base[:wc[p]] + off[p]                           # every vehicle its own (shifted) table
+    pid = np.arange(n, dtype=np.int32)
+    s0 = np.tile(np.concatenate([g["state"], [0.0, 0.0]])[:, None], (1, n))
+    s0[0] += rng.uniform(-3, 3, n)
+    s0[3:7] = s0[0] / 0.308309813617345
+    s0[7] += rng.normal(0, 0.03, n)
+    s0[8] = base[5, 0] + off[:, 0] + rng.uniform(0.0, 1.5, n)
+    s0[9] = base[5, 1] + off[:, 1] + rng.normal(0, 0.3, n)
+    c0 = np.zeros((6, n))
+    c0[2] = s0[0]
+    c0[3] = 25.0
+    term, cs, log = vm.closed_loop(s0, c0, wp, 60, wcount=wc, path_id=pid, gains=gains, log=True)
+    ot, oc, olog = oracle.closed_loop(oracle.default_params(), cp, s0, c0, wp, wc, pid, dt, 60, log=True, nthreads=8)
+    assert np.array_equal(log[:, 14], olog[:, 14]), "target indices must match the oracle exactly"
+    assert parity(term, ot, F64_TOL) <= 1e-9
+    cu, out = vm.controller_update(s0, c0, wp, wcount=wc, path_id=pid, gains=gains)
+    assert np.array_equal(out[1], log[0, 14])
+    t32, _ = vm.closed_loop(s0.astype(np.float32), c0.astype(np.float32), wp.astype(np.float32), 60, wcount=wc,
+                            path_id=pid, gains=gains)
+    parity(t32, ot, F32_TOL, "closed loop fp32, private tables")
+
+
 # ---- "next" row 2: collision check + best-path selection ---------------------------------------
 def test_g10_collision_and_selection(gpu_vm, pkg, oracle):
     """63 cases from the reference (its planner's own 3 calls + 60 obstacle re-placements):
