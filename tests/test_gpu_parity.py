@@ -895,3 +895,25 @@ def test_heterogeneous_fleet_rollout(gpu_vm, pkg, oracle, workloads):
     assert np.array_equal(one, gpu_vm(dt, params=classes[0]).rollout(s0, tab, path_id=pid))
     with pytest.raises(ValueError):
         vm.rollout_fleet(s0, tab, classes, vid + 3, path_id=pid)
+
+
+def test_integration_md_ctypes_stub_runs_verbatim():
+    """The raw ctypes stub printed in INTEGRATION.md section 3, executed as written, reproduces KAT-1
+    (SURVEY.md section 8a): the integration document is executable."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"## 3\. Raw `ctypes` stub.*?```python\n(.*?)```", src, re.S).group(1)
+    import torch  # noqa: F401  (one HIP runtime per process, as the stub's comment says)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        ns = {}
+        exec(code, ns)
+        st = [25.0, 0, 0] + [25.0 / 0.308309813617345] * 4 + [0, 0, 0]
+        out = ns["planar_model_RK4"](st, [0] * 4, [1.0] * 4, [0.02, 0.02, 0, 0], 0.0, 0.0, 1e-4)
+    finally:
+        os.chdir(cwd)
+    assert abs(out[7] + 0.030200889513079934) < 1e-9 and abs(out[8] - 2.944897222404597) < 1e-9
+    assert abs(out[0][0] - 2.4999996979914723e+01) < 1e-9
