@@ -897,6 +897,31 @@ def test_heterogeneous_fleet_rollout(gpu_vm, pkg, oracle, workloads):
         vm.rollout_fleet(s0, tab, classes, vid + 3, path_id=pid)
 
 
+def test_general_tire_shape_path(gpu_vm, pkg, oracle, workloads):
+    """Tire sets outside the reflection form of the FAST step (a shape factor above 2, a negative
+    stiffness factor: kernel variant CS = false, full pi-reduction and signed atan) through the plain
+    rollout kernels (LDS-shared and per-rollout controls), fp64 and fp32, against the oracle."""
+    VP = pkg.VehicleParameters
+    a, b = VP(CFL=2.3), VP(BFL=-18.0)
+    a.CRL = a.CRR = 2.6                                                # per-wheel overrides, as vehicle_model.py:237-242 does
+    for veh in (a, b):
+        n, H, dt = 1500, 80, 1e-3
+        s0, tab, pid = workloads.config3(n, H, np.float64)
+        tab[:, :, 0] *= 6.0                                            # steering up to 0.36 rad: slips beyond B s = 1
+        vm = gpu_vm(dt, params=veh)
+        want = oracle.rollout(oracle.params_from(veh), s0, tab, dt, path_id=pid)
+        assert parity(vm.rollout(s0, tab, path_id=pid), want, F64_TOL) <= 1e-9
+        # fp32 bar: north_star's 1e-3 (inside parity), and no worse than 3x what the plain-C float oracle
+        # itself loses on these dynamics (a negative stiffness factor makes them error-amplifying)
+        o32 = oracle.rollout(oracle.params_from(veh), s0.astype(np.float32), tab.astype(np.float32), dt, path_id=pid)
+        floor = (np.abs(o32 - want) / np.abs(want).max(axis=1, keepdims=True)).max()
+        e32 = parity(vm.rollout(s0.astype(np.float32), tab.astype(np.float32), path_id=pid), want, F32_TOL)
+        assert e32 <= max(3e-5, 3 * floor), (e32, floor)
+        ctrl = workloads.expand_shared_controls(tab, pid)
+        e32 = parity(vm.rollout(s0.astype(np.float32), ctrl.astype(np.float32)), want, F32_TOL)
+        assert e32 <= max(3e-5, 3 * floor), (e32, floor)
+
+
 def test_integration_md_ctypes_stub_runs_verbatim():
     """The raw ctypes stub printed in INTEGRATION.md section 3, executed as written, reproduces KAT-1
     (SURVEY.md section 8a): the integration document is executable."""
