@@ -24,7 +24,7 @@ SOURCES = [("vdyn_kernels_f32.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
            ("vdyn_capi.hip", [])]
 HEADERS = [os.path.join(CSRC, h) for h in ("vdyn_kernels.hip", "vdyn_device.hpp", "vdyn_internal.hpp",
                                            "vdyn_fastmath.hpp", "vdyn_packed.hpp", "vdyn_controls.hpp",
-                                           "vdyn_quad.hpp", "vdyn_lattice.hpp")] + \
+                                           "vdyn_quad.hpp", "vdyn_quad_packed.hpp", "vdyn_lattice.hpp")] + \
           [os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-fno-fast-math", "-Wall", "-Wno-unused-function",

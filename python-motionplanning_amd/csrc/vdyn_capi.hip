@@ -226,7 +226,7 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     VDYN_HIP(h, hipSetDevice(h->device));
     vdyn::RolloutArgs<T> b = a;
     // 0 = automatic: wheel-parallel while it is measurably faster (tools/sweep_lanes.py at the
-    // sustained clock, against the packed lane kernel: fp32 1.35x up to 16384 rollouts, 0.8x at
+    // sustained clock, against the packed lane kernel: fp32 1.6x up to 16384 rollouts, 0.94x at
     // 24576; fp64 2.3x up to 16384, 1.46x at 32768, 1.0x at 40960)
     const int64_t auto_max = sizeof(T) == 4 ? 16384 : 32768;
     b.lanes_per_rollout = h->lanes_per_rollout == 0 ? (a.n <= auto_max ? 4 : 1) : h->lanes_per_rollout;

@@ -11,6 +11,7 @@
 #include "vdyn_packed.hpp"
 #include "vdyn_controls.hpp"
 #include "vdyn_quad.hpp"
+#include "vdyn_quad_packed.hpp"
 #include "vdyn_lattice.hpp"
 
 namespace vdyn {
@@ -243,6 +244,8 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
     const bool active = (gid >> 2) < n;
     const int64_t r = active ? (gid >> 2) : n - 1;
     const WheelLane<T> L = make_wheel_lane<T>(P, q);
+    QuadEngine<T> qe;
+    qe.init(P, L);
 
     QuadState<T> s;
     s.U = state0[r];
@@ -282,7 +285,7 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
                 tq = c[(int64_t)(4 + q) * stride];
                 mu = c[(int64_t)(8 + q) * stride];
             }
-            rk4_advance_quad<T, CS>(P, L, s, ax, ay, delta, tq, mu, h);
+            qe.template advance<CS>(P, L, s, ax, ay, delta, tq, mu, h);
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;

@@ -1,0 +1,218 @@
+// vdyn_quad_packed.hpp -- the wheel-parallel fp32 FAST step (vdyn_quad.hpp) on packed pairs.
+//
+// One lane = one wheel, so there is no second wheel to pair up with; what pairs up are the 2-D
+// quantities of the lane itself: corner velocity (vx, vy), slip (sx, sy), tire force (fx, fy),
+// (U, V), (x, y), (wz, yaw), (sin, cos), (axc, ayc).  Rotations and cross products are one or two
+// VOP3P instructions each (pk_cross / pk_hi_conj / pk_rot90 with the per-half sign bits), the
+// atan range split is the compare-free clamp indicator of vdyn_packed.hpp, and the integrator
+// state is three pairs + the lane's wheel speed.  457 -> ~320 VALU instructions per RK4 step, all
+// of it on a wave's critical path (these kernels run where the chip is mostly empty).
+//
+// Semantics: those of rk4_step_quad<float, false, true> (vdyn_quad.hpp).  Only the CS = true FAST
+// step is specialised; CS = false and the SAFE redo use the scalar code unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vdyn_packed.hpp"
+#include "vdyn_quad.hpp"
+
+namespace vdyn {
+
+__device__ __forceinline__ f2 pk_rot90(f2 a, f2 b)        // (-a.y b.x, a.x b.x): a rotated by +90 deg, times b.x
+{
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <typename T>
+struct QuadEngine {
+    __device__ __forceinline__ void init(const DevParams<T> &, const WheelLane<T> &) {}
+    template <bool CS>
+    __device__ __forceinline__ void advance(const DevParams<T> &P, const WheelLane<T> &L, QuadState<T> &s, T &ax,
+                                            T &ay, T delta, T tq, T mu, T h) const
+    {
+        rk4_advance_quad<T, CS>(P, L, s, ax, ay, delta, tq, mu, h);
+    }
+};
+
+template <>
+struct QuadEngine<float> {
+    f2 sck[3];        // (sin, cos) kernel coefficients, as in PkConsts
+    f2 lv;            // (side T/2, lever): corner velocity = (U, V) + lv wz   (:261-271)
+    f2 inv_m2;
+    float neg_rw_Jw, inv_Jw, moment_x;   // -rw / Jw; 1 / Jw; side T/2 (yaw moment arm of fx, :378)
+
+    __device__ __forceinline__ void init(const DevParams<float> &P, const WheelLane<float> &L)
+    {
+        const float sks[3] = {-1.951163867e-04f, 8.332134224e-03f, -1.666665375e-01f};
+        const float cks[3] = {2.443367339e-05f, -1.388732577e-03f, 4.166664556e-02f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sck[i] = f2{sks[i], cks[i]};
+            asm volatile("" : "+v"(sck[i]));
+        }
+        float hT = P.half_T, im = P.inv_m, iJ = P.inv_Jw, r_w = P.rw;
+        asm("" : "+v"(hT), "+v"(im), "+v"(iJ), "+v"(r_w));     // see PkParams::init on why
+        moment_x = L.side * hT;
+        lv = f2{moment_x, L.lever};
+        inv_m2 = f2{im, im};
+        inv_Jw = iJ;
+        neg_rw_Jw = -r_w * iJ;
+    }
+
+    __device__ __forceinline__ f2 sincos_k(float r) const
+    {
+        const float u = r * r;
+        const f2 u2 = f2{u, u};
+        f2 p = fma2(sck[0], u2, sck[1]);
+        p = fma2(p, u2, sck[2]);
+        return fma2(f2{r, u} * u2, p, f2{r, ::fmaf(-0.5f, u, 1.0f)});
+    }
+    __device__ __forceinline__ f2 sincos_full(float x, bool &ok) const      // fm::sincos_mid on a pair
+    {
+        const float k = __builtin_rintf(x * 0.636619772367581343076f);
+        float r = ::fmaf(-k, 1.57079637050628662109375f, x);
+        r = ::fmaf(-k, -4.37113900018624283e-08f, r);
+        r = ::fmaf(-k, -1.7151245100059e-15f, r);
+        const f2 sc = sincos_k(r);
+        const int q = (int)k;
+        const bool swap = (q & 1) != 0;
+        const float s0 = swap ? sc.y : sc.x, c0 = swap ? sc.x : sc.y;
+        const unsigned fs = ((unsigned)(q & 2)) << 30, fc = ((unsigned)((q + 1) & 2)) << 30;
+        ok = ok && (::fabsf(x) <= fm::kSincosMidLimit);
+        return f2{__uint_as_float(__float_as_uint(s0) ^ fs), __uint_as_float(__float_as_uint(c0) ^ fc)};
+    }
+
+    struct Lane3 {
+        f2 uv, wy, xy;    // (U, V), (wz, yaw), (x, y)
+        float w;          // this lane's wheel speed
+    };
+
+    // One derivative evaluation (vehicle_model.py:220-425) for this lane's wheel + the replicated chassis.
+    __device__ __forceinline__ void deriv(const DevParams<float> &P, const WheelLane<float> &L, f2 dsc, float muFz,
+                                          float tqJ, const Lane3 &s, f2 sc, Lane3 &k, f2 &acc_c) const
+    {
+        const f2 wz2 = f2{s.wy.x, s.wy.x};
+        const f2 vv = fma2(lv, wz2, s.uv);                                // corner velocity, chassis frame
+        const f2 tv = fma2(vv, f2{dsc.y, dsc.y}, pk_cross(vv, dsc));      // :274-281 (vx, vy), tire frame
+        const float rvx = fm::rcp(tv.x);
+        const float sx = ::fmaf(P.rw, s.w, -tv.x) * rvx;                  // :284-287
+        const float sy = -tv.y * ::fabsf(rvx);                            // :290-293 (quirk Q4)
+        const float s2 = ::fmaf(sx, sx, ::fmaf(sy, sy, 1e-30f));          // :296-299, quirk Q5 (see tire_force2x2)
+        const float rs = fm::rsq(s2);
+        const float xs = L.B * (s2 * rs), ix = rs * L.invB;
+        // sin(C atan(x)), x >= 0: reduced argument min(x, 1/x), atan = p + [x > 1] (pi/2 - 2 p)
+        const float t = ::fminf(xs, ix);
+        const float ind = __builtin_amdgcn_fmed3f(::fmaf(xs, 0x1p100f, -0x1p100f), 0.0f, 1.0f);
+        const float u = t * t;
+        float p = 2.872858429e-03f;
+        p = ::fmaf(p, u, -1.616817340e-02f);
+        p = ::fmaf(p, u, 4.286647215e-02f);
+        p = ::fmaf(p, u, -7.520283014e-02f);
+        p = ::fmaf(p, u, 1.064901948e-01f);
+        p = ::fmaf(p, u, -1.420586258e-01f);
+        p = ::fmaf(p, u, 1.999291778e-01f);
+        p = ::fmaf(p, u, -3.333308995e-01f);
+        p = ::fmaf(p * u, t, t);
+        const float th = ::fmaf(ind, ::fmaf(-2.0f, p, 1.57079637050628662109375f), p);
+        const float g = fm::sin_0_pi(L.C * th) * rs * muFz;               // mu / s times Fz (quirk Q1 in muFz)
+        const f2 ft = f2{sx, sy} * f2{g, g};                              // :351-360 (fxt, fyt)
+        const f2 fc = fma2(ft, f2{dsc.y, dsc.y}, pk_rot90(ft, dsc));      // :363-373 (fx, fy), chassis frame
+        const float Sfx = quad_sum(fc.x), Sfy = quad_sum(fc.y);
+        const float Mz = quad_sum(::fmaf(L.lever, fc.y, moment_x * fc.x));   // :378
+        const f2 cross = pk_cross(s.uv, s.wy);                            // (V wz, -U wz)
+        k.uv = fma2(inv_m2, f2{Sfx, Sfy}, cross);                         // :376-377
+        acc_c = k.uv - cross;                                             // :413-414
+        k.wy = f2{P.inv_Izz * Mz, s.wy.x};
+        k.w = ::fmaf(neg_rw_Jw, L.front ? ft.x : fc.x, tqJ);              // :379-382, quirk Q2
+        k.xy = fma2(f2{s.uv.x, s.uv.x}, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));   // :384-385
+    }
+
+    // FAST RK4 step (vehicle_model.py:427-445); false when the lane left the validated range.
+    __device__ __forceinline__ bool step(const DevParams<float> &P, const WheelLane<float> &L, const Lane3 &s, f2 axy,
+                                         float delta, float tq, float mu, float h, Lane3 &sn, f2 &axy_n) const
+    {
+        bool ok = ::fabsf(delta) <= fm::kSincosKernelLimit;
+        const f2 dsc = sincos_k(delta);                                   // (sin, cos) of the steering angle
+        const float Fz = ::fmaf(L.ky, axy.y, ::fmaf(L.kx, axy.x, L.Fz0)); // :255-258 (quirk Q3)
+        const float muFz = mu * Fz, tqJ = tq * inv_Jw;
+        const float hh = 0.5f * h;
+        const f2 hh2 = f2{hh, hh}, h2 = f2{h, h}, two = f2{2.0f, 2.0f};
+        const f2 sc0 = sincos_full(s.wy.y, ok);
+        Lane3 k, acc, st;
+        f2 a, as2, sc;
+#define VDYN_L3_EACH(OP) OP(uv) OP(wy) OP(xy)
+#define VDYN_ROT(d)                                                              \
+    {                                                                            \
+        const float d_ = (d);                                                    \
+        const f2 dd = sincos_k(d_);                                              \
+        ok = ok && (::fabsf(d_) <= fm::kSincosKernelLimit);                      \
+        sc = fma2(sc0, f2{dd.y, dd.y}, pk_cross(sc0, dd));                       \
+    }
+        deriv(P, L, dsc, muFz, tqJ, s, sc0, k, a);                        // K1
+        as2 = a;
+#define VDYN_L3_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
+        VDYN_L3_EACH(VDYN_L3_1)
+        acc.w = k.w; st.w = ::fmaf(hh, k.w, s.w);
+        VDYN_ROT(hh * k.wy.y)
+        deriv(P, L, dsc, muFz, tqJ, st, sc, k, a);                        // K2
+        as2 = fma2(two, a, as2);
+#define VDYN_L3_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
+        VDYN_L3_EACH(VDYN_L3_2)
+        acc.w = ::fmaf(2.0f, k.w, acc.w); st.w = ::fmaf(hh, k.w, s.w);
+        VDYN_ROT(hh * k.wy.y)
+        deriv(P, L, dsc, muFz, tqJ, st, sc, k, a);                        // K3
+        as2 = fma2(two, a, as2);
+#define VDYN_L3_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
+        VDYN_L3_EACH(VDYN_L3_3)
+        acc.w = ::fmaf(2.0f, k.w, acc.w); st.w = ::fmaf(h, k.w, s.w);
+        VDYN_ROT(h * k.wy.y)
+        deriv(P, L, dsc, muFz, tqJ, st, sc, k, a);                        // K4
+        as2 = as2 + a;
+        const float sixth = 1.0f / 6.0f, h6 = h * sixth;
+        const f2 h62 = f2{h6, h6};
+#define VDYN_L3_4(f) sn.f = fma2(h62, acc.f + k.f, s.f);
+        VDYN_L3_EACH(VDYN_L3_4)
+        sn.w = ::fmaf(h6, acc.w + k.w, s.w);
+#undef VDYN_L3_1
+#undef VDYN_L3_2
+#undef VDYN_L3_3
+#undef VDYN_L3_4
+#undef VDYN_ROT
+#undef VDYN_L3_EACH
+        axy_n = as2 * f2{sixth, sixth};
+        return ok;
+    }
+
+    template <bool CS>
+    __device__ __forceinline__ void advance(const DevParams<float> &P, const WheelLane<float> &L,
+                                            QuadState<float> &s, float &ax, float &ay, float delta, float tq,
+                                            float mu, float h) const
+    {
+        if (!CS) {
+            rk4_advance_quad<float, CS>(P, L, s, ax, ay, delta, tq, mu, h);
+            return;
+        }
+        Lane3 S, Sn;
+        S.uv = f2{s.U, s.V};
+        S.wy = f2{s.wz, s.yaw};
+        S.xy = f2{s.x, s.y};
+        S.w = s.w;
+        f2 axy_n;
+        const bool ok = step(P, L, S, f2{ax, ay}, delta, tq, mu, h, Sn, axy_n);
+        QuadState<float> sn;
+        sn.U = Sn.uv.x; sn.V = Sn.uv.y; sn.wz = Sn.wy.x; sn.yaw = Sn.wy.y; sn.x = Sn.xy.x; sn.y = Sn.xy.y;
+        sn.w = Sn.w;
+        float axn = axy_n.x, ayn = axy_n.y;
+        const bool okq = quad_all(ok);                                    // the whole quad redoes the step together
+        if (__builtin_expect(__any(!okq) != 0, 0)) {
+            if (!okq) rk4_step_quad<float, true, CS>(P, L, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
+        }
+        s = sn;
+        ax = axn;
+        ay = ayn;
+    }
+};
+
+}  // namespace vdyn
