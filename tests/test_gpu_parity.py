@@ -922,6 +922,46 @@ def test_general_tire_shape_path(gpu_vm, pkg, oracle, workloads):
         assert e32 <= max(3e-5, 3 * floor), (e32, floor)
 
 
+def test_rollout_fuzz_shapes_layouts_kernels(pkg, oracle, workloads):
+    """48 seeded combinations of batch size (1..3000, ragged against the 64-lane wave and the
+    256-thread workgroup), horizon (0..40), control layout (per-rollout / shared with 1..40 paths),
+    k (2 / 12), precision and kernel (lane / wheel-parallel), each against the oracle."""
+    rng = np.random.default_rng(2024)
+    p = oracle.default_params()
+    for case in range(48):
+        n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 3000))]))
+        H = int(rng.choice([0, 1, 2, int(rng.integers(3, 41))]))
+        k = int(rng.choice([2, 12]))
+        shared = bool(rng.integers(0, 2))
+        P = int(rng.integers(1, 41))
+        dtype = np.float64 if case % 3 else np.float32
+        lanes = 4 if case % 4 == 1 else 1
+        dt = 1e-3
+        s0, _ = workloads.config2(int(np.ceil(np.sqrt(n))), 1)
+        s0 = s0[:, :n].copy()
+        s0[0] += rng.uniform(-5, 5, n)
+        s0[3:7] = s0[0] / 0.308309813617345 * (1 + rng.uniform(-0.01, 0.01, (4, n)))
+        s0[7] = rng.uniform(-3, 3, n)
+        nrow = P if shared else n
+        if k == 2:
+            c = np.stack([rng.uniform(-0.3, 0.3, (H, nrow)), rng.uniform(-200, 400, (H, nrow))], axis=1)
+        else:
+            c = np.concatenate([rng.uniform(-0.3, 0.3, (H, 2, nrow)), rng.uniform(-0.05, 0.05, (H, 2, nrow)),
+                                rng.uniform(-200, 400, (H, 4, nrow)), rng.uniform(0.6, 1.0, (H, 4, nrow))], axis=1)
+        vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, lanes_per_rollout=lanes)
+        if shared:
+            pid = rng.integers(0, P, n).astype(np.int32)
+            tab = np.ascontiguousarray(np.transpose(c, (2, 0, 1)))            # [P][H][k]
+            want = oracle.rollout(p, s0, tab, dt, path_id=pid) if H else s0
+            got = vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid)
+        else:
+            want = oracle.rollout(p, s0, c, dt) if H else s0
+            got = vm.rollout(s0.astype(dtype), c.astype(dtype))
+        tol = F64_TOL if dtype == np.float64 else F32_TOL
+        assert got.shape == (12, n), (case, got.shape)
+        parity(got, want, tol, f"fuzz case {case}: n={n} H={H} k={k} shared={shared} P={P} {dtype.__name__} lanes={lanes}")
+
+
 def test_integration_md_ctypes_stub_runs_verbatim():
     """The raw ctypes stub printed in INTEGRATION.md section 3, executed as written, reproduces KAT-1
     (SURVEY.md section 8a): the integration document is executable."""
