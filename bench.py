@@ -431,6 +431,26 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
         vm.rollout(s0_h, tab, path_id=pid_h)
     t = (time.perf_counter() - t0) / 5
     ex["host_abi_pcie_inclusive_f32"] = {"steps_per_s": n / t, "ms": t * 1e3}
+    # two independent batches in flight: launches alternate between two HIP streams (one handle each),
+    # so the next batch's dispatch, table staging and first loads overlap the tail of the previous one
+    # and the two waves a SIMD then holds run out of phase (tools/two_stream_probe.py)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    vms = [vm, type(vm)(2.906, np.deg2rad(30), DT, device=vm.device)]
+    tabd2 = torch.from_numpy(tab).to(dev)
+
+    def burst(k):
+        for i in range(k):
+            with torch.cuda.stream(streams[i & 1]):
+                vms[i & 1].rollout(s0, tabd2, path_id=pid)
+    torch.cuda.synchronize()
+    burst(200)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    burst(400)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 400
+    ex["two_streams_65536x200_f32"] = {"steps_per_s": n / t, "ms_per_launch": t * 1e3,
+                                       "note": "independent batches alternating between two HIP streams (wall time)"}
     # occupancy sweep of the main kernel: where the chip fills up
     sweep = {}
     for mult in (2, 4, 8):
