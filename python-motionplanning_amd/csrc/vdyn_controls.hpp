@@ -235,23 +235,24 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
     T px, py;
     wp.get(best_i, px, py);
     if (wp.seg != nullptr) {
-        // same sequential sum as the reference, eight precomputed segment lengths per trip.  The
+        // same sequential sum as the reference, sixteen precomputed segment lengths per trip.  The
         // running total never decreases (lengths are >= 0), so a trip whose LAST partial sum is
-        // still short of the lookahead cannot contain the crossing: eight dependent adds and one
+        // still short of the lookahead cannot contain the crossing: sixteen dependent adds and one
         // compare, and only the trip that ends the walk is resolved entry by entry.
         bool done = total >= G.lookahead;
-        for (int i0 = best_i + 1; i0 < wp.W && !done; i0 += 8) {
-            T t[8];
+        constexpr int kTrip = 16;
+        for (int i0 = best_i + 1; i0 < wp.W && !done; i0 += kTrip) {
+            T t[kTrip];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = wp.seg_at(min(i0 + k, wp.W - 1));
+            for (int k = 0; k < kTrip; ++k) t[k] = wp.seg_at(min(i0 + k, wp.W - 1));
             t[0] = total + t[0];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = t[k - 1] + t[k];
-            const bool whole = i0 + 8 <= wp.W && t[7] < G.lookahead;      // NaN: false -> resolved below
+            for (int k = 1; k < kTrip; ++k) t[k] = t[k - 1] + t[k];
+            const bool whole = i0 + kTrip <= wp.W && t[kTrip - 1] < G.lookahead;      // NaN: false -> resolved below
             if (__any(!whole)) {
                 if (!whole) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < kTrip; ++k) {
                         const bool take = !done && (i0 + k) < wp.W;
                         total = take ? t[k] : total;
                         ce = take ? i0 + k : ce;
@@ -260,8 +261,8 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
                 }
             }
             if (whole) {
-                total = t[7];
-                ce = i0 + 7;
+                total = t[kTrip - 1];
+                ce = i0 + kTrip - 1;
             }
         }
         wp.get(ce, px, py);
