@@ -123,11 +123,11 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             c = cn;
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
-                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;   // written once: streaming stores
 #pragma unroll
-                for (int i = 0; i < 10; ++i) row[(int64_t)i * n] = s[i];
-                row[10 * n] = ax;
-                row[11 * n] = ay;
+                for (int i = 0; i < 10; ++i) __builtin_nontemporal_store(s[i], row + (int64_t)i * n);
+                __builtin_nontemporal_store(ax, row + 10 * n);
+                __builtin_nontemporal_store(ay, row + 11 * n);
             }
         }
     }
@@ -212,11 +212,11 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
             eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
             c = cn;
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
-                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;   // written once: streaming stores
 #pragma unroll
-                for (int i = 0; i < 10; ++i) row[(int64_t)i * n] = s[i];
-                row[10 * n] = ax;
-                row[11 * n] = ay;
+                for (int i = 0; i < 10; ++i) __builtin_nontemporal_store(s[i], row + (int64_t)i * n);
+                __builtin_nontemporal_store(ax, row + 10 * n);
+                __builtin_nontemporal_store(ay, row + 11 * n);
             }
         }
     }
@@ -583,18 +583,21 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         if (DATALOG) eng.template advance_diag<true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
         else eng.template advance<true, CS>(P, s, ax, ay, delta, tq, P.mu, h);
         if (DATALOG && active) {
+            // written once, never read back by this kernel: streaming (non-temporal) stores
             T *row = datalog + (int64_t)t * 45 * n + r;
-            row[0] = (T)(phase + t) * h;                                          // drive.py:145
+#define VDYN_NT(idx, val) __builtin_nontemporal_store((T)(val), row + (int64_t)(idx) * n)
+            VDYN_NT(0, (T)(phase + t) * h);                                       // drive.py:145
 #pragma unroll
-            for (int i = 0; i < 10; ++i) row[(int64_t)(1 + i) * n] = s[i];       // :146
+            for (int i = 0; i < 10; ++i) VDYN_NT(1 + i, s[i]);                    // :146
 #pragma unroll
-            for (int i = 0; i < 10; ++i) row[(int64_t)(11 + i) * n] = sd[i];     // :147
-            row[(int64_t)21 * n] = c.delta;                                       // :148
+            for (int i = 0; i < 10; ++i) VDYN_NT(11 + i, sd[i]);                  // :147
+            VDYN_NT(21, c.delta);                                                 // :148
 #pragma unroll
-            for (int i = 0; i < 4; ++i) row[(int64_t)(22 + i) * n] = c.tau;      // :149
+            for (int i = 0; i < 4; ++i) VDYN_NT(22 + i, c.tau);                   // :149
 #pragma unroll
-            for (int i = 0; i < 18; ++i) row[(int64_t)(26 + i) * n] = o18.v[i];  // :150
-            row[(int64_t)44 * n] = c.cte;                                         // :151
+            for (int i = 0; i < 18; ++i) VDYN_NT(26 + i, o18.v[i]);               // :150
+            VDYN_NT(44, c.cte);                                                   // :151
+#undef VDYN_NT
         }
         if (log != nullptr && active) {
             T *row = log + (int64_t)t * 16 * n + r;
