@@ -5,13 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (torch.distributed.run as a child process, before this process touches torch or HIP).
+
 One "step" = one pass of the hot path over one batch: ONE launch of the rollout
-kernel over BASELINE.json configs[2] -- 65536 rollouts (9363 egos x 7 lattice
-paths) x 200 RK4 steps, fp32, dt = 1e-3, per-path controls shared through LDS --
-on every GPU (weak scaling: each rank integrates its own 65536-rollout slice of a
-world*65536 workload), followed for N > 1 by the RCCL all-gather of the terminal
-states, which is the only exchange the path has.  Inputs are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line.
+kernel over BASELINE.json configs[2] -- 65536 rollouts (ego r // 7, lattice path r % 7)
+x 200 RK4 steps, fp32, dt = 1e-3, per-path controls shared through LDS -- on every GPU,
+followed for N > 1 by the exchange of the terminal states (RCCL all-gather), which is the only
+exchange the path has.  Ranks own contiguous blocks of WHOLE egos
+(workloads.shard_egos / distributed.ShardedRollout): weak scaling (default) integrates
+N x 9362 egos = N x 65534 rollouts, --strong splits the fixed 65536.  Every shard runs the
+lane-per-rollout kernel, so shard + gather is bit for bit the single-GPU result.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -28,6 +33,7 @@ if ROOT not in sys.path:
 
 N_PER_GPU = 65536
 HORIZON = 200
+NUM_PATHS = 7
 DT = 1e-3
 # SURVEY.md section 8(d) contract figures (also DESIGN.md section 5)
 BYTES_PER_STEP_SHARED = 96.0 / HORIZON          # (12 in + 12 out) * 4 B / H, controls from LDS
@@ -37,7 +43,7 @@ HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s 
 VALU_PEAK_TFLOPS = 157.3                        # fp32 vector peak (= fp32 MFMA peak)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -48,14 +54,24 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations")
     ap.add_argument("--strong", action="store_true",
-                    help="fixed 65536 rollouts split over the ranks (BASELINE configs[3] as worded) instead "
-                         "of the default weak scaling; small shards use the wheel-parallel kernel")
+                    help="fixed 65536 rollouts split over the ranks by whole egos (BASELINE configs[3] as worded) "
+                         "instead of the default weak scaling; same lane-per-rollout kernel, so the gathered "
+                         "result is bit for bit the single-GPU one")
+    ap.add_argument("--wheel-parallel", action="store_true",
+                    help="four lanes per rollout (shorter serial chain for small shards; agrees with the "
+                         "lane-per-rollout kernel to rounding, not bit for bit): the labelled second number of --strong")
+    ap.add_argument("--exchange", choices=("rccl",), default="rccl",
+                    help="N>1 exchange of terminal states: RCCL all-gather (default) or direct peer copies "
+                         "(hipMemcpyPeerAsync into every peer's slot on a copy stream: no CU-resident copy kernel)")
+    ap.add_argument("--rollouts-per-gpu", type=int, default=N_PER_GPU, help=argparse.SUPPRESS)
+    ap.add_argument("--horizon", type=int, default=HORIZON, help=argparse.SUPPRESS)
+    ap.add_argument("--dump-gathered", default=None, help=argparse.SUPPRESS)   # tests: every rank saves what it holds
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 code path (RCCL all-gather of terminal states, overlapped with the "
                          "next launch) even with one rank: rehearsal of the multi-GPU path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each all-gather before the next launch (A/B of the overlap)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def timed_launches(fn, n, torch, warm_ms=40.0):
@@ -152,8 +168,70 @@ def pmc_summary():
         return {}
 
 
-def main():
-    args = parse()
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, script=None, port=None):
+    """`python3 bench.py --gpus N` as typed (no torchrun around it): start N fresh child ranks
+    with torch.distributed.run and return their exit code.  Called BEFORE this process imports
+    torch or touches HIP -- a process that has initialised the GPU is never re-executed; the
+    children are ordinary subprocesses and rank 0's JSON line goes straight to our stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+           script or os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def total_rollouts(world, per_gpu, strong):
+    """Rollouts of the whole job.  One GPU: BASELINE configs[2] as named (65536 = 9362 egos x 7
+    lattice paths + one ego with 2).  Strong scaling: the same 65536, split.  Weak scaling on
+    N > 1 GPUs: N x (per_gpu // 7) WHOLE egos, so that every rank integrates the same number of
+    complete egos (9362 -> 65534 rollouts, 256 workgroups: one wave per SIMD, as on one GPU)."""
+    if strong or world == 1:
+        return per_gpu
+    return world * (per_gpu // NUM_PATHS) * NUM_PATHS
+
+
+class HipCompute:
+    """The product path: VehicleModel.rollout on this rank's MI355X (HIP kernels behind the C ABI)."""
+
+    def __init__(self, pkg, local_rank, lanes_per_rollout, dt):
+        import torch
+        assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.device = torch.device("cuda", local_rank)
+        self.vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, device=local_rank, lanes_per_rollout=lanes_per_rollout)
+        self.backend = "nccl"
+
+    def rollout(self, s0, tab, pid):
+        return self.vm.rollout(s0, tab, path_id=pid)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def mark(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()          # on torch's current stream = the stream the kernels are enqueued on
+        return e
+
+    @staticmethod
+    def elapsed_s(a, b):
+        return a.elapsed_time(b) * 1e-3
+
+
+def run(args, compute_factory=None):
+    """One rank of the bench.  ``compute_factory(pkg, local_rank, lanes_per_rollout, dt)`` builds
+    the per-rank compute (default: HipCompute); tests/test_bench_multirank.py passes a CPU
+    stand-in to rehearse THIS function's sharding, exchange, timing and JSON with gloo ranks."""
     import torch
     import torch.distributed as dist
 
@@ -161,73 +239,70 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    pkg = importlib.import_module("python-motionplanning_amd")
+    W = pkg.workloads
+    D = importlib.import_module("python-motionplanning_amd.distributed")
+    H, per_gpu = args.horizon, args.rollouts_per_gpu
+    # lane-per-rollout on every shard: shard + gather is then bit for bit the single-GPU result
+    # (SURVEY 8e); --wheel-parallel is the explicitly labelled second number for small shards
+    lanes = 4 if args.wheel_parallel else 1
+    cp = (compute_factory or HipCompute)(pkg, local_rank, lanes, DT)
+    dev = cp.device
     collective = world > 1 or args.force_collective
     if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+        kw = {"device_id": dev} if cp.backend == "nccl" else {}
+        dist.init_process_group(cp.backend, rank=rank, world_size=world, **kw)
 
-    pkg = importlib.import_module("python-motionplanning_amd")
-    W = pkg.workloads
-    n_local = N_PER_GPU // world if args.strong else N_PER_GPU
-    # strong scaling: shards shrink with the rank count -> let the library pick the kernel (0 = auto)
-    vm = pkg.VehicleModel(2.906, np.deg2rad(30), DT, device=local_rank, lanes_per_rollout=0 if args.strong else 1)
-
-    # workload: world * n_local rollouts, this rank's contiguous slice, resident in HBM
-    s0_all, tab, pid_all = W.config3(n_local * world, HORIZON, np.float32)
-    lo, hi = rank * n_local, (rank + 1) * n_local
+    # workload: whole egos per rank (workloads.shard_egos through ShardedRollout), resident on the device
+    n_total = total_rollouts(world, per_gpu, args.strong)
+    sh = D.ShardedRollout(n_total)
+    assert sh.world == world and sh.rank == rank
+    lo, hi, n_local = sh.lo, sh.hi, sh.n_local
+    s0_all, tab, pid_all = W.config3(n_total, H, np.float32)
     s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
     pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
-    gathered = torch.empty((world * 12, n_local), dtype=torch.float32, device=dev) if collective else None
     del s0_all, pid_all
+    xch = D.make_exchange(args.exchange, sh, rows=12, like=s0) if collective else None
 
     kern_ev = []
-    pending = []   # [(work, terminal)] of the all-gather in flight; the tensor stays referenced until waited for
-
-    def drain():
-        while pending:
-            pending.pop()[0].wait()
 
     def step(record):
         if record:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-        term = vm.rollout(s0, tabd, path_id=pid)
+            a = cp.mark()
+        term = cp.rollout(s0, tabd, pid)
         if record:
-            b.record()
-            kern_ev.append((a, b))
+            kern_ev.append((a, cp.mark()))
         if collective:
-            # the exchange step of BASELINE configs[3]: every rank ends up with all terminal states.
-            # RCCL runs it on its own stream; the previous step's gather is only waited for AFTER this
-            # step's rollout has been queued, so gather k overlaps rollout k+1 (all K gathers still
-            # complete inside the timed region: fence() drains the last one)
-            drain()
-            pending.append((dist.all_gather_into_tensor(gathered, term, async_op=True), term))
+            # the exchange step of BASELINE configs[3]: every rank ends up with all terminal states
+            # (rank-major blocks [world][12][n_pad]).  It runs beside the compute stream; the previous
+            # step's exchange is only waited for AFTER this step's rollout has been queued, so exchange
+            # k overlaps rollout k+1 (all K exchanges still complete inside the timed region: fence())
+            xch.wait()
+            xch.start(term)
             if args.no_overlap:
-                drain()
+                xch.wait()
         return term
 
     def fence():
-        drain()
         if collective:
+            xch.wait()
             dist.barrier()
-        torch.cuda.synchronize()
+        cp.sync()
 
     # clock ramp (reported in the JSON as `prewarm`): the same step, untimed, for a fixed wall time
     prewarm_launches = 0
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
         for _ in range(16):
-            vm.rollout(s0, tabd, path_id=pid)     # kernel only: a wall-time loop must not contain a collective
+            cp.rollout(s0, tabd, pid)              # kernel only: a wall-time loop must not contain a collective
         prewarm_launches += 16                     # (ranks would issue different numbers of them)
-        torch.cuda.synchronize()
+        cp.sync()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -242,46 +317,59 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(term).all()), "non-finite terminal states"
+    gathered_ok = None
+    if collective:
+        # the exchanged result, checked once outside the timed region: this rank's own block came back
+        # unchanged and every block is finite
+        full = xch.result()
+        gathered_ok = bool(torch.equal(full[:, lo:hi], term)) and bool(torch.isfinite(full).all()) \
+            and tuple(full.shape) == (12, n_total)
+        if args.dump_gathered:
+            np.save(os.path.join(args.dump_gathered, f"gathered_rank{rank}.npy"), full.cpu().numpy())
 
-    kern_s = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) * 1e-3
-    units = world * n_local * HORIZON * args.steps
-    steps_per_launch = n_local * HORIZON
+    durs = np.array([cp.elapsed_s(a, b) for a, b in kern_ev]) if kern_ev else np.array([float("nan")])
+    kern_s, kern_med = float(durs.mean()), float(np.median(durs))
+    units = n_total * H * args.steps
+    steps_per_launch = n_local * H
     out = {
         "metric": "RK4 vehicle-steps/sec", "value": units / elapsed, "unit": "vehicle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "rollouts_per_s": world * n_local * args.steps / elapsed,
+        "rollouts_per_s": n_total * args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
         "prewarm": {"ms": args.prewarm_ms, "launches": prewarm_launches,
                     "why": "GPU clock ramp after idle, before the W untimed warm-up steps"},
-        # the same job without the exchange step (SURVEY 8d config 4 asks for both): kernel time only
-        "value_excluding_collective": world * n_local * HORIZON / kern_s,
+        # the same job without the exchange step (SURVEY 8d config 4 asks for both): rank 0's kernel time only
+        "value_excluding_collective": n_total * H / kern_s,
+        "world_seen": sh.world, "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
+        "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
+                                                 "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok},
         "config": {
-            "workload": "BASELINE configs[2]: 65536 rollouts per GPU (ego r//7, lattice path r%7) x 200 "
-                        "RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared via LDS; "
-                        "N>1: + RCCL all-gather of terminal states [12][65536] per rank, gather k overlapped with rollout k+1",
-            "rollouts_per_gpu": n_local, "horizon": HORIZON, "dt": DT, "controls": "shared[7][200][2]",
+            "workload": f"BASELINE configs[2]: {per_gpu} rollouts per GPU (ego r//7, lattice path r%7; whole egos per "
+                        f"rank: {n_total} in all) x {H} RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared "
+                        "via LDS" + ("; fixed total split over the ranks (configs[3] as worded)" if args.strong else "")
+                        + ("; + exchange of terminal states [12][n_local] per rank, exchange k overlapped with "
+                           "rollout k+1" if collective else ""),
+            "rollouts_per_gpu": n_local, "horizon": H, "dt": DT, "controls": "shared[7][200][2]",
+            "lanes_per_rollout": lanes,
         },
     }
     if rank == 0:
-        pmc = pmc_summary()
-        algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * n_local
-        ach = algo_bytes / kern_s / 1e9
-        out["roofline"] = {
-            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
-            "kernel": "rollout_kernel<float,2,LDS-shared>", "kernel_ms": kern_s * 1e3,
-            "algorithmic_bytes_per_launch": algo_bytes,
-            "note": "register-resident scalar-nonlinear kernel: HBM and MFMA are both idle by design; "
-                    "the binding resource is VALU issue (roofline_valu)",
-        }
+        pmc = pmc_summary() if cp.backend == "nccl" else {}
+        # the binding roofline of this kernel is VALU issue, priced as 850 flop per
+        # vehicle-step against the fp32 vector peak
         tf = FLOP_PER_STEP * steps_per_launch / kern_s / 1e12
-        out["roofline_valu"] = {
+        algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * n_local
+        out["roofline"] = {
             "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / VALU_PEAK_TFLOPS, "flop_per_vehicle_step": FLOP_PER_STEP,
+            "frac": tf / VALU_PEAK_TFLOPS, "traffic": pmc.get("hbm_bytes_per_launch"),
+            "flop_per_vehicle_step": FLOP_PER_STEP, "kernel": "rollout_kernel<float,2,LDS-shared>",
+            "kernel_ms": kern_s * 1e3, "kernel_ms_median": kern_med * 1e3,
             "kernel_steps_per_s": steps_per_launch / kern_s,
+            "note": "register-resident scalar-nonlinear kernel: MFMA has no contraction to work on and HBM "
+                    "carries 0.48 B per vehicle-step (roofline_hbm); VALU issue binds",
         }
         ipw = pmc.get("valu_insts_per_wave_per_rk4_step")
         if ipw:
@@ -291,22 +379,41 @@ def main():
             # 65536 rollouts give) cannot issue faster than one per 4 cycles = 0.5 of that peak
             issue = ipw * (steps_per_launch / 64.0) / kern_s
             peak_issue = 1024 * 2.4e9 / 2
-            out["roofline_valu"].update({
-                "valu_insts_per_wave_step": ipw, "issue_rate": issue, "issue_peak": peak_issue,
-                "issue_frac": issue / peak_issue, "issue_frac_of_one_wave_per_simd_ceiling": issue / (peak_issue / 2)})
-        if world == 1 and not args.no_extra and not args.strong:
-            out["extra"] = extra_configs(vm, W, torch, dev, s0, tab, pid)
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(W, term.cpu().numpy() if not args.strong else None)
+            out["roofline"].update({
+                "valu_insts_per_wave_step": ipw, "cycles_per_inst": pmc.get("wave_cycles_per_valu_inst"),
+                "issue_rate": issue, "issue_peak": peak_issue, "issue_frac": issue / peak_issue,
+                "issue_frac_of_one_wave_per_simd_ceiling": issue / (peak_issue / 2),
+                "pmc_source": "profiles/pmc_summary.json (" + str(pmc.get("tag")) + ")"})
+        ach = algo_bytes / kern_s / 1e9
+        out["roofline_hbm"] = {
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": algo_bytes,
+        }
+        if world == 1 and cp.backend == "nccl" and not args.no_extra and not args.strong:
+            out["extra"] = extra_configs(cp.vm, W, torch, dev, s0, tab, pid)
+        if world == 1 and cp.backend == "nccl" and not args.no_cpu_baseline:
+            full_size = not args.strong and per_gpu == N_PER_GPU and H == HORIZON
+            cb = cpu_baseline(W, term.cpu().numpy() if full_size else None)
             err = cb.pop("fp32_state_error")
             if err is not None:
                 out["fp32_state_error"] = err
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["value"] / cb["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if collective:
         dist.barrier()
+        xch.close()
         dist.destroy_process_group()
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python3 bench.py --gpus N`: become the launcher (nothing below has touched HIP)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    run(args)
 
 
 def extra_configs(vm, W, torch, dev, s0, tab, pid):

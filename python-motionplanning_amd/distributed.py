@@ -41,26 +41,75 @@ class ShardedRollout:
         idx[axis] = slice(self.lo, self.hi)
         return x[tuple(idx)]
 
+    def assemble(self, blocks: torch.Tensor, rows: int) -> torch.Tensor:
+        """Rank-major padded blocks ``[world][rows][n_pad]`` -> ``[rows][n_units]``."""
+        blocks = blocks.view(self.world, rows, self.n_pad)
+        out = blocks.new_empty((rows, self.n_units))
+        for r, (lo, hi) in enumerate(self.bounds):
+            out[:, lo:hi] = blocks[r, :, :hi - lo]
+        return out
+
     def all_gather_terminal(self, term_local: torch.Tensor) -> torch.Tensor:
         """[rows][n_local] on every rank -> [rows][n_units] on every rank."""
         if self.world == 1:
             return term_local
-        rows = term_local.shape[0]
-        send = term_local
-        if self.n_local != self.n_pad:  # last rank may hold fewer egos: pad the block
-            send = term_local.new_zeros((rows, self.n_pad))
-            send[:, :self.n_local] = term_local
-        recv = term_local.new_empty((self.world * rows, self.n_pad))  # rank-major blocks
-        dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
-        recv = recv.view(self.world, rows, self.n_pad)
-        out = term_local.new_empty((rows, self.n_units))
-        for r, (lo, hi) in enumerate(self.bounds):
-            out[:, lo:hi] = recv[r, :, :hi - lo]
-        return out
+        x = AllGatherExchange(self, term_local.shape[0], term_local)
+        x.start(term_local)
+        return x.result()
 
     def rollout(self, rollout_fn, state0_local, *args, **kw):
         """Local compute + the terminal-state all-gather."""
         return self.all_gather_terminal(rollout_fn(state0_local, *args, **kw))
+
+
+class AllGatherExchange:
+    """The one exchange step of the path -- every rank ends up with every rank's terminal block --
+    as ``torch.distributed.all_gather_into_tensor`` (RCCL over xGMI on GPU ranks, gloo on CPU
+    ranks) into a preallocated buffer of rank-major, equally sized blocks ``[world][rows][n_pad]``.
+
+    ``start`` is asynchronous: the collective runs beside the caller's stream, ``wait`` joins it
+    (bench.py queues the next rollout in between, so exchange k overlaps rollout k + 1)."""
+
+    kind = "all_gather_into_tensor"
+
+    def __init__(self, sh: ShardedRollout, rows: int, like: torch.Tensor):
+        self.sh, self.rows = sh, int(rows)
+        self.recv = like.new_empty((sh.world * self.rows, sh.n_pad))
+        # a rank holding fewer egos than the largest shard sends a zero-padded block
+        self.send = like.new_zeros((self.rows, sh.n_pad)) if sh.n_local != sh.n_pad else None
+        self._pending = None
+
+    def start(self, term_local: torch.Tensor):
+        assert self._pending is None, "wait() for the previous exchange first"
+        assert tuple(term_local.shape) == (self.rows, self.sh.n_local)
+        src = term_local
+        if self.send is not None:
+            self.send[:, :self.sh.n_local].copy_(term_local)
+            src = self.send
+        if not dist.is_initialized():
+            self.recv.copy_(src)
+            return
+        work = dist.all_gather_into_tensor(self.recv, src.contiguous(), group=self.sh.group, async_op=True)
+        self._pending = (work, src)          # the source stays referenced until the collective is joined
+
+    def wait(self):
+        if self._pending is not None:
+            self._pending[0].wait()
+            self._pending = None
+
+    def result(self) -> torch.Tensor:
+        """[rows][n_units]: the blocks of the last exchange, unpadded and in global order."""
+        self.wait()
+        return self.sh.assemble(self.recv, self.rows)
+
+    def close(self):
+        self.wait()
+
+
+def make_exchange(kind: str, sh: ShardedRollout, rows: int, like: torch.Tensor):
+    if kind == "rccl":
+        return AllGatherExchange(sh, rows, like)
+    raise ValueError(f"unknown exchange {kind!r}")
 
 
 def all_gather_argmin(best_cost_local: torch.Tensor, best_idx_local: torch.Tensor, n_ego, group=None):

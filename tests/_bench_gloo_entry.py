@@ -1,0 +1,45 @@
+"""Rank entry of tests/test_bench_multirank.py: bench.py's own ``run`` -- sharding by whole egos,
+exchange, barrier-bracketed timing, JSON -- on CPU ranks (gloo), with the per-rank compute
+replaced by the oracle (test infrastructure; the product has no CPU path).  Started by bench.py's
+own ``spawn_ranks``."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import bench  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+class OracleCompute:
+    backend = "gloo"
+
+    def __init__(self, pkg, local_rank, lanes_per_rollout, dt):
+        import time
+        self.device = torch.device("cpu")
+        self.dt, self.p, self._t = dt, O.default_params(), time.perf_counter
+        self.lanes = lanes_per_rollout
+
+    def rollout(self, s0, tab, pid):
+        t = O.rollout(self.p, s0.numpy().astype(np.float64), tab.numpy().astype(np.float64), self.dt,
+                      path_id=pid.numpy(), nthreads=1)
+        return torch.from_numpy(t.astype(np.float32))
+
+    def sync(self):
+        pass
+
+    def mark(self):
+        return self._t()
+
+    @staticmethod
+    def elapsed_s(a, b):
+        return b - a
+
+
+if __name__ == "__main__":
+    args = bench.parse()
+    bench.run(args, compute_factory=OracleCompute)

@@ -1,0 +1,82 @@
+"""bench.py's own N > 1 path on CPU: its launcher (`spawn_ranks`, i.e. what `python3 bench.py
+--gpus N` does when no torchrun is around it), its whole-ego sharding, its exchange and its JSON,
+with two gloo ranks and the oracle standing in for the per-rank HIP compute
+(tests/_bench_gloo_entry.py).  SURVEY.md section 8(e): shard + gather == single, bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENTRY = os.path.join(REPO, "tests", "_bench_gloo_entry.py")
+
+
+def _launch(tmp_path, world, extra):
+    argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-extra",
+            "--no-cpu-baseline", "--horizon", "12", "--dump-gathered", str(tmp_path), *extra]
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.spawn_ranks(%d, %r, script=%r))" % (REPO, world, argv, ENTRY))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"rank 0 prints ONE JSON line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode,per_gpu", [("weak", 70), ("strong", 65), ("strong", 70)])
+def test_bench_two_ranks_shard_by_whole_egos_and_gather_bitwise(tmp_path, mode, per_gpu, oracle, workloads):
+    import bench
+    world = 2
+    extra = ["--rollouts-per-gpu", str(per_gpu)] + (["--strong"] if mode == "strong" else [])
+    out = _launch(tmp_path, world, extra)
+    n_total = bench.total_rollouts(world, per_gpu, mode == "strong")
+    assert out["n_gpus"] == world and out["world_seen"] == world and out["scaling"] == mode
+    assert out["rollouts_total"] == n_total
+    shards = out["shards"]
+    assert shards == [list(workloads.shard_egos(n_total, world, r)) for r in range(world)]
+    assert shards[0][0] == 0 and shards[-1][1] == n_total
+    assert all(lo % workloads.NUM_PATHS == 0 for lo, _ in shards), "ranks own whole egos"
+    assert out["exchange"]["verified"] is True and out["exchange"]["overlapped"] is True
+    assert out["config"]["lanes_per_rollout"] == 1, "shards run the lane-per-rollout kernel (bitwise contract)"
+    assert out["value"] > 0 and out["steps"] == 2 and out["unit"] == "vehicle-steps/s"
+    if mode == "weak":
+        assert n_total == world * (per_gpu // 7) * 7 and len({hi - lo for lo, hi in shards}) == 1
+    # what every rank holds after the last exchange == the single-process result, bit for bit
+    s0, tab, pid = workloads.config3(n_total, 12, np.float32)
+    single = oracle.rollout(oracle.default_params(), s0.astype(np.float64), tab.astype(np.float64), 1e-3,
+                            path_id=pid, nthreads=1).astype(np.float32)
+    for r in range(world):
+        got = np.load(tmp_path / f"gathered_rank{r}.npy")
+        assert got.dtype == np.float32 and np.array_equal(got, single)
+
+
+def test_total_rollouts_keeps_one_wave_per_simd():
+    import bench
+    assert bench.total_rollouts(1, 65536, False) == 65536
+    for w in (2, 4, 8):
+        n = bench.total_rollouts(w, 65536, False)
+        assert n == w * 65534 and n % 7 == 0
+        assert bench.total_rollouts(w, 65536, True) == 65536
+
+
+def test_self_launch_happens_before_torch_is_imported():
+    """`python3 bench.py --gpus 2` as typed: the parent must become the launcher without importing
+    torch (no HIP initialisation in a process that then starts others)."""
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2']\n"
+            "import subprocess\n"
+            "def fake_run(cmd, env=None):\n"
+            "    assert 'torch' not in sys.modules, 'torch imported before the launch'\n"
+            "    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd\n"
+            "    assert cmd[-2:] == ['--gpus', '2'] and '127.0.0.1' in cmd\n"
+            "    assert env.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'\n"
+            "    class R: returncode = 7\n"
+            "    return R()\n"
+            "subprocess.run = fake_run\n"
+            "runpy.run_path(%r, run_name='__main__')\n" % os.path.join(REPO, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 7, res.stderr[-2000:]      # the child's exit code is ours

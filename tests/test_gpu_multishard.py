@@ -1,0 +1,64 @@
+"""GPU (-m gpu): the multi-GPU contract checked on ONE MI355X, and BASELINE configs[4] at its
+full size.
+
+SURVEY.md section 8(e): ranks own contiguous blocks of whole egos, run the same lane-per-rollout
+kernel, and the gathered result must be bit for bit the single-GPU result.  An 8-GPU node is not
+available to the tests, so the 8 shards `workloads.shard_egos(65536, 8, r)` are integrated one
+after another on cuda:0 and their concatenation is compared with one 65536-rollout launch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_eight_shards_one_after_another_equal_the_single_launch_bitwise(gpu_vm, workloads, dtype):
+    import torch
+    dev = torch.device("cuda:0")
+    n, H, world = 65536, 200, 8
+    s0, tab, pid = workloads.config3(n, H, dtype)
+    vm = gpu_vm(1e-3)                                   # lanes_per_rollout = 1: what bench.py runs on every shard
+    s0d, tabd, pidd = (torch.from_numpy(a).to(dev) for a in (s0, tab, pid))
+    single = vm.rollout(s0d, tabd, path_id=pidd)
+    parts, covered = [], 0
+    for r in range(world):
+        lo, hi = workloads.shard_egos(n, world, r)
+        assert lo == covered and lo % workloads.NUM_PATHS == 0
+        covered = hi
+        parts.append(vm.rollout(s0d[:, lo:hi].contiguous(), tabd, path_id=pidd[lo:hi].contiguous()))
+    assert covered == n
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, dim=1), single), "shard + concatenate must be bitwise the single launch"
+    # the weak-scaling shard of bench.py (9362 whole egos = 65534 rollouts) is a prefix of the same batch
+    lo, hi = workloads.shard_egos(8 * 65534, 8, 0)
+    assert (lo, hi) == (0, 65534)
+    assert torch.equal(vm.rollout(s0d[:, :hi].contiguous(), tabd, path_id=pidd[:hi].contiguous()), single[:, :hi])
+
+
+def test_mpc_config5_full_size_vs_oracle(gpu_vm, oracle, workloads):
+    """BASELINE configs[4] as worded: 1024 egos x 512 candidates x 50 steps, dt = 2e-3, argmin on
+    the device.  Cost model after collision_checker.py:175,190-196 (terminal distance to the goal;
+    non-finite candidates disqualified; strict '<' scan, lowest index on ties)."""
+    E, C, H, dt = 1024, 512, 50, 2e-3
+    ego, cand, goal = workloads.config5(E, C, H)                      # fp32, the bench workload
+    vm = gpu_vm(dt)
+    bc, bi, cost = vm.mpc_argmin(ego, cand, goal, w_delta=workloads.MPC_W_DELTA, return_costs=True)
+    e64, c64, g64 = (a.astype(np.float64) for a in (ego, cand, goal))
+    p = oracle.default_params()
+    obc, obi, ocost = oracle.mpc_argmin(p, e64, c64, g64, dt, workloads.MPC_W_DELTA,
+                                        nthreads=oracle.max_threads(), return_costs=True)
+    assert np.isfinite(cost).all() and cost.shape == (E, C)
+    worst = np.abs(cost - ocost).max()
+    assert worst <= 1e-3, f"fp32 costs vs fp64 oracle: {worst:.3e}"
+    assert np.array_equal(bi, cost.argmin(axis=1)), "device argmin == argmin of its own costs (first minimum)"
+    assert np.array_equal(bc, cost.min(axis=1))
+    rows = np.arange(E)
+    gap = ocost[rows, bi] - obc                                        # the winner's true cost above the true minimum
+    assert (gap >= 0).all() and gap.max() <= 2 * worst + 1e-6, f"winner not a minimiser up to fp32 noise: {gap.max():.3e}"
+    print(f"\n  config5 full: fp32 cost err {worst:.2e}, argmin agrees with fp64 oracle on {(bi == obi).mean():.1%}, "
+          f"worst winner gap {gap.max():.2e}")
+    # fp64 on the device: the very same argmin as the oracle
+    bc64, bi64, cost64 = vm.mpc_argmin(e64, c64, g64, w_delta=workloads.MPC_W_DELTA, return_costs=True)
+    assert np.abs(cost64 - ocost).max() <= 1e-9
+    assert np.array_equal(bi64, obi)
+    assert np.abs(bc64 - obc).max() <= 1e-9
