@@ -131,6 +131,8 @@ __device__ __forceinline__ float abs_t(float a) { return ::fabsf(a); }
 __device__ __forceinline__ double abs_t(double a) { return ::fabs(a); }
 __device__ __forceinline__ float tiny_t(float) { return 1e-30f; }     // sqrt = 1e-15: (B s)^2 below fp32 ulp
 __device__ __forceinline__ double tiny_t(double) { return 1e-280; }   // sqrt = 1e-140
+__device__ __forceinline__ float steer_limit_t(float) { return fm::kSincosMidLimit; }      // the range Math<T, false>::sincos validates
+__device__ __forceinline__ double steer_limit_t(double) { return fm64::kSincosMidLimit; }
 __device__ __forceinline__ float sqrt_t(float a) { return ::sqrtf(a); }
 __device__ __forceinline__ double sqrt_t(double a) { return ::sqrt(a); }
 
@@ -146,12 +148,21 @@ struct StepInv {
 // K2 = true: the drive.py:142-143 pattern -- delta[1] == delta[0], rear angles exactly
 // 0, so one sincos serves the front axle and the rear rotations are the identity
 // (x*1 + y*0 == x in IEEE) and are skipped.
-template <typename T, bool K2, bool SAFE>
+// PRE (FAST only): sin / cos of the front steering angle arrive precomputed (sd0, cd0), evaluated by
+// the same Math<T, false>::sincos when an LDS-shared control table was staged.
+template <typename T, bool K2, bool SAFE, bool PRE = false>
 __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T delta[4], const T tq[4],
-                                              const T mu[4], T ax_prev, T ay_prev, StepInv<T> &c, bool &ok)
+                                              const T mu[4], T ax_prev, T ay_prev, StepInv<T> &c, bool &ok,
+                                              T sd0 = T(0), T cd0 = T(1))
 {
     using M = Math<T, SAFE>;
-    M::sincos(delta[0], &c.sd[0], &c.cd[0], ok);
+    if (PRE && !SAFE) {
+        c.sd[0] = sd0;
+        c.cd[0] = cd0;
+        ok = ok && (abs_t(delta[0]) <= steer_limit_t(T(0)));
+    } else {
+        M::sincos(delta[0], &c.sd[0], &c.cd[0], ok);
+    }
     if (K2) {
         c.sd[1] = c.sd[0];
         c.cd[1] = c.cd[0];
@@ -282,15 +293,15 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
 // sn[10], (axn, ayn), the latter the 1-2-2-1 averages of axc, ayc (:442-443).
 // DIAG: also state_dot (:440) and the averaged outputs (:441).
 // Returns false for a lane that left the validated range of the FAST path.
-template <typename T, bool K2, bool DIAG, bool SAFE, bool CS>
+template <typename T, bool K2, bool DIAG, bool SAFE, bool CS, bool PRE = false>
 __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T ax, T ay, const T delta[4],
                                          const T tq[4], const T mu[4], T h, T sn[10], T &axn, T &ayn,
-                                         T *state_dot, Outputs18<T> *outputs)
+                                         T *state_dot, Outputs18<T> *outputs, T sd0 = T(0), T cd0 = T(1))
 {
     using M = Math<T, SAFE>;
     bool ok = true;
     StepInv<T> c;
-    make_step_inv<T, K2, SAFE>(P, delta, tq, mu, ax, ay, c, ok);
+    make_step_inv<T, K2, SAFE, PRE>(P, delta, tq, mu, ax, ay, c, ok, sd0, cd0);
     const T hh = T(0.5) * h;
     T k[10], acc[10], st[10], a1, a2, asx, asy;
     Outputs18<T> o, osum;
@@ -349,13 +360,14 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 // One step for one lane: the FAST path, then SAFE for the lanes that need it.
 // The outer test is wave-uniform (one scalar branch, normally not taken); the
 // inner one restricts the redo to the lanes that asked for it.
-template <typename T, bool K2, bool DIAG, bool CS>
+template <typename T, bool K2, bool DIAG, bool CS, bool PRE = false>
 __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                             const T tq[4], const T mu[4], T h, T *state_dot,
-                                            Outputs18<T> *outputs)
+                                            Outputs18<T> *outputs, T sd0 = T(0), T cd0 = T(1))
 {
     T sn[10], axn, ayn;
-    const bool ok = rk4_step<T, K2, DIAG, false, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+    const bool ok = rk4_step<T, K2, DIAG, false, CS, PRE>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs,
+                                                          sd0, cd0);
     if (Math<T, false>::kHasRangeLimit) {
         if (__builtin_expect(__any(!ok) != 0, 0)) {
             if (!ok) rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);

@@ -26,6 +26,17 @@ constexpr int kLdsBudget = 48 * 1024;  // bytes of control table staged per chun
 template <typename T, int K>
 struct Ctrl {
     T delta[4], tq[4], mu[4];
+    T sd0 = T(0), cd0 = T(1);   // sin / cos of delta[0] when the staged table carries them (set_pre)
+    // entry of a table staged by stage_control_table_pre: (delta_front, torque_all, sin delta, cos delta)
+    __device__ __forceinline__ void set_pre(const DevParams<T> &P, const T *e)
+    {
+        delta[0] = delta[1] = e[0];
+        delta[2] = delta[3] = T(0);
+        sd0 = e[2];
+        cd0 = e[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { tq[i] = e[1]; mu[i] = P.mu[i]; }
+    }
     __device__ __forceinline__ void set(const DevParams<T> &P, const T *c, int64_t stride)
     {
         if (K == 2) {
@@ -59,11 +70,42 @@ __device__ __forceinline__ void stage_control_table(T *__restrict__ tab, const T
     }
 }
 
+// The same for k = 2 tables, with the steering angle's (sin, cos) computed here, once per table entry,
+// instead of by every lane at every step: tab [tc][p][4] = (delta_front, torque_all, sin, cos), one
+// 16-byte LDS read per lane and step.  `eng.steer_sincos` is the function the step itself would call,
+// so LDS-shared and per-rollout controls still give bit-identical rollouts.
+template <typename T, typename ENG>
+__device__ __forceinline__ void stage_control_table_pre(T *__restrict__ tab, const T *__restrict__ ctrl, int Pn, int H,
+                                                        int t0, int tc_n, const ENG &eng)
+{
+    for (int p = 0; p < Pn; ++p) {
+        const T *src = ctrl + ((int64_t)p * H + t0) * 2;
+        for (int j = threadIdx.x; j < tc_n; j += kBlock) {
+            const T d = src[2 * j], tq = src[2 * j + 1];
+            T sd, cd;
+            eng.steer_sincos(d, sd, cd);
+            T *dst = tab + ((int64_t)j * Pn + p) * 4;
+            dst[0] = d;
+            dst[1] = tq;
+            dst[2] = sd;
+            dst[3] = cd;
+        }
+    }
+}
+
 // H zero-order-hold RK4 steps per lane (the loop of drive.py:114,141-143 with
 // vehicle_model.py:427-445 inside).  DIAG additionally returns the last step's
 // state_dot / outputs (used for H = 1: the planar_model_RK4 drop-in).
 // CS: Pacejka shape factors in [0, 2] and B >= 0 (true of any realistic tire, and of the
 // reference's 1.5047): sin's argument stays in [0, pi] and takes the short reflection form.
+// k = 2 tables staged in LDS carry (sin, cos) of the steering angle per entry (not for the
+// diagnostic single-step variant, which is launch-latency bound)
+template <int K, int LAYOUT, bool DIAG> constexpr bool rollout_table_pre() { return K == 2 && LAYOUT == 1 && !DIAG; }
+template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds_per_step(int P)
+{
+    return (size_t)P * (rollout_table_pre<K, LAYOUT, DIAG>() ? 4 : K) * sizeof(T);
+}
+
 template <typename T, int K, int LAYOUT, bool DIAG, bool CS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
@@ -78,11 +120,9 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     const bool active = gid < n;
     const int64_t r = active ? gid : n - 1;  // idle lanes shadow the last rollout, stores masked
 
-    T s[10], ax, ay;
+    typename StepEngine<T>::State X;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) s[i] = state0[(int64_t)i * n + r];
-    ax = state0[10 * n + r];
-    ay = state0[11 * n + r];
+    for (int i = 0; i < 12; ++i) X.set(i, state0[(int64_t)i * n + r]);
 
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);  // ids outside [0, P) are clamped, never read out of bounds
@@ -90,13 +130,15 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     T sd[10];
     Outputs18<T> o18;
     StepEngine<T> eng;
+    constexpr bool PRE = rollout_table_pre<K, LAYOUT, DIAG>();
     if (!DIAG) eng.init(P);
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
             __syncthreads();  // previous chunk fully consumed
-            stage_control_table<T, K>(tab, ctrl, Pn, H, t0, tc_n);
+            if (PRE) stage_control_table_pre<T>(tab, ctrl, Pn, H, t0, tc_n, eng);
+            else stage_control_table<T, K>(tab, ctrl, Pn, H, t0, tc_n);
             __syncthreads();
         }
         // Step t + 1's controls are fetched before step t is integrated, so that their latency (LDS
@@ -106,6 +148,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
         auto fetch = [&](Ctrl<T, K> &c, int tc) __attribute__((always_inline)) {
             const int t = t0 + tc;
             if (LAYOUT == 0) c.set(P, ctrl + ((int64_t)t * K) * n + r, n);
+            else if (PRE) c.set_pre(P, tab + ((int64_t)tc * Pn + pid) * 4);
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
         };
@@ -118,25 +161,31 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             Ctrl<T, K> cn;
             fetch(cn, min(tc + 1, tc_n - 1));
 
-            if (DIAG) rk4_advance<T, K == 2, true, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
-            else eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
+            if (DIAG) {
+                T s[10], ax = X.get(10), ay = X.get(11);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) s[i] = X.get(i);
+                rk4_advance<T, K == 2, true, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h, sd, &o18);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) X.set(i, s[i]);
+                X.set(10, ax);
+                X.set(11, ay);
+            } else {
+                eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+            }
             c = cn;
 
             if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;   // written once: streaming stores
 #pragma unroll
-                for (int i = 0; i < 10; ++i) __builtin_nontemporal_store(s[i], row + (int64_t)i * n);
-                __builtin_nontemporal_store(ax, row + 10 * n);
-                __builtin_nontemporal_store(ay, row + 11 * n);
+                for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), row + (int64_t)i * n);
             }
         }
     }
 
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) terminal[(int64_t)i * n + r] = s[i];
-        terminal[10 * n + r] = ax;
-        terminal[11 * n + r] = ay;
+        for (int i = 0; i < 12; ++i) terminal[(int64_t)i * n + r] = X.get(i);
         if (DIAG) {
             if (state_dot_out != nullptr && H > 0) {
 #pragma unroll
@@ -949,7 +998,7 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
     int chunk = a.H > 0 ? a.H : 1;
     size_t lds = 0;
     if (LAYOUT == 1) {
-        const size_t per_step = (size_t)a.P * K * sizeof(T);
+        const size_t per_step = rollout_lds_per_step<T, K, LAYOUT, DIAG>(a.P);
         chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
         lds = (size_t)chunk * per_step;
     }
@@ -1033,7 +1082,8 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
 {
     if (a.n <= 0) return hipSuccess;
     int layout = a.layout;
-    if (layout == VDYN_CTRL_SHARED && (size_t)a.P * a.k * sizeof(T) > (size_t)kLdsBudget) layout = 2;
+    // one step of the table must fit the LDS budget (k = 2 tables are staged 4 wide, see rollout_table_pre)
+    if (layout == VDYN_CTRL_SHARED && (size_t)a.P * (a.k == 2 ? 4 : a.k) * sizeof(T) > (size_t)kLdsBudget) layout = 2;
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
     const bool cs = shape_factors_small(p);
     if (a.lanes_per_rollout == 4 && !diag) {

@@ -62,6 +62,8 @@ struct PkConsts {
     f2 big, neg2, tiny;  // 2^100 (indicator scale), -2, 1e-30 (floor of s^2, quirk Q5)
     f2 side;             // (-1, +1): left / right wheel (quirk Q8)
     f2 sck[3];           // (sin, cos) kernel coefficients on |r| <= pi/4 (sincos_kernel), one pair per degree
+    f2 cs[5];            // cos(z) = Q(z^2) on |z| <= pi/2, highest degree first (CS: sin(y) = cos(y - pi/2), y in [0, pi])
+    f2 rot_a, rot_b, rot_c;   // (-1/6, 1/24), (1, -1/2), (0, 1): (sin d, cos d) of a stage's small yaw increment
 
     __device__ __forceinline__ void pin(f2 &v, float c)
     {
@@ -93,6 +95,15 @@ struct PkConsts {
             sck[i] = f2{sks[i], cks[i]};
             asm volatile("" : "+v"(sck[i]));
         }
+        // cos(z) on |z| <= pi/2 as a degree-4 polynomial in z^2 (tools/fit_polys.py: fit error 5.1e-8,
+        // fp32 Horner within 1.8e-7 absolute)
+        const float cc[5] = {2.312937249e-05f, -1.385257230e-03f, 4.166342318e-02f, -4.999989867e-01f, 9.999999404e-01f};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) pin(cs[i], cc[i]);
+        rot_a = f2{-1.0f / 6.0f, 1.0f / 24.0f};
+        rot_b = f2{1.0f, -0.5f};
+        rot_c = f2{0.0f, 1.0f};
+        asm volatile("" : "+v"(rot_a), "+v"(rot_b), "+v"(rot_c));
     }
 };
 
@@ -174,14 +185,22 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
         VDYN_BOTH(q) th[q] = f2{b0[q] ? (::copysignf(pio2, x[q].x) - p[q].x) : p[q].x,
                                b1[q] ? (::copysignf(pio2, x[q].y) - p[q].y) : p[q].y};
     }
-    VDYN_BOTH(q) y[q] = C[q] * th[q];
     if (CS) {
-        // sin on [0, pi] by reflection about pi/2 (vdyn_fastmath.hpp, sin_0_pi)
-        f2 m[2];
-        VDYN_BOTH(q) m[q] = K.pi_hi - y[q];
-        VDYN_BOTH(q) m[q] = m[q] + K.pi_lo;
-        VDYN_BOTH(q) r[q] = f2{::fminf(y[q].x, m[q].x), ::fminf(y[q].y, m[q].y)};
-    } else {
+        // y = C theta lies in [0, pi]: sin(y) = cos(y - pi/2), an even polynomial in z = y - pi/2 on
+        // |z| <= pi/2 -- no reflection, no min, and z comes out of the fma that forms y.  Absolute
+        // accuracy 1.8e-7 (the reflected odd polynomial was 2 ulp relative): the force it scales,
+        // s_x mu Fz / s, inherits an absolute error of 2e-7 Fz ~ 1e-3 N per tire.
+        f2 z[2], q4[2];
+        VDYN_BOTH(q) z[q] = fma2(C[q], th[q], -K.pio2);
+        VDYN_BOTH(q) w[q] = z[q] * z[q];
+        VDYN_BOTH(q) q4[q] = fma2(K.cs[0], w[q], K.cs[1]);
+        VDYN_BOTH(q) q4[q] = fma2(q4[q], w[q], K.cs[2]);
+        VDYN_BOTH(q) q4[q] = fma2(q4[q], w[q], K.cs[3]);
+        VDYN_BOTH(q) out[q] = fma2(q4[q], w[q], K.cs[4]);
+        return;
+    }
+    VDYN_BOTH(q) y[q] = C[q] * th[q];
+    {
         VDYN_BOTH(q) kk[q] = y[q] * K.inv_pi;
         VDYN_BOTH(q) kk[q] = f2{__builtin_rintf(kk[q].x), __builtin_rintf(kk[q].y)};
         VDYN_BOTH(q) r[q] = fma2(-kk[q], K.pi_hi, y[q]);
@@ -193,7 +212,7 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
     VDYN_BOTH(q) ps[q] = fma2(ps[q], w[q], K.sn[3]);
     VDYN_BOTH(q) w[q] = r[q] * w[q];
     VDYN_BOTH(q) out[q] = fma2(w[q], ps[q], r[q]);
-    if (!CS) {
+    {
         VDYN_BOTH(q) {
             const unsigned f0 = ((unsigned)(int)kk[q].x) << 31, f1 = ((unsigned)(int)kk[q].y) << 31;
             out[q] = f2{__uint_as_float(__float_as_uint(out[q].x) ^ f0), __uint_as_float(__float_as_uint(out[q].y) ^ f1)};
@@ -292,12 +311,15 @@ __device__ __forceinline__ f2 sincos_steer2(const PkConsts &K, float d, bool &ok
     return sincos_kernel2(K, d);
 }
 
-// (sin, cos) of (yaw0 + d) from sc0 = (sin, cos) of yaw0: rotation by the small increment d.
-__device__ __forceinline__ f2 stage_sincos2(const PkConsts &K, f2 sc0, float d, bool &ok)
+// (sin d, cos d) of a stage's yaw increment d = (h/2 or h) wz, |d| <= kStageYawLimit: the Taylor
+// forms d (1 - d^2/6) and 1 - d^2/2 + d^4/24 (relative error 8e-9 and 1.3e-12 at the limit) in
+// two packed operations.  Larger increments (wz > 31 rad/s at dt = 1e-3) send the lane to SAFE.
+constexpr float kStageYawLimit = 0.03125f;
+__device__ __forceinline__ f2 stage_rot2(const PkConsts &K, float d)
 {
-    const f2 dd = sincos_kernel2(K, d);                         // (sin d, cos d)
-    ok = ok && (::fabsf(d) <= fm::kSincosKernelLimit);
-    return fma2(sc0, f2{dd.y, dd.y}, pk_cross(sc0, dd));        // (s0 cd + c0 sd, c0 cd - s0 sd)
+    const float u = d * d;
+    const f2 a = fma2(f2{u, u}, K.rot_a, K.rot_b);             // (1 - u/6, -1/2 + u/24)
+    return fma2(f2{d, u}, a, K.rot_c);                         // (d (1 - u/6), 1 + u (-1/2 + u/24))
 }
 
 struct State5 {
@@ -320,8 +342,11 @@ struct Diag2 {
     f2 fx[2], fy[2], s[2], fxt, fyt;
 };
 
-// vehicle_model.py:220-425 on pairs.  sc = (sin, cos) of the stage yaw.
-template <bool K2, bool CS, bool DIAG = false>
+// vehicle_model.py:220-425 on pairs.  sc = (sin, cos) of the stage yaw MINUS the yaw the step
+// started from: k.xy is the global-frame velocity (:384-385) expressed in the frame of the initial
+// yaw, and rk4_step2 rotates the 1-2-2-1 sum into the global frame once (a rotation is linear, so
+// R(yaw0) sum_j w_j R(d_j) u_j == sum_j w_j R(yaw0 + d_j) u_j).  FIRST: the first stage, d = 0.
+template <bool K2, bool CS, bool DIAG = false, bool FIRST = false>
 __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
                                               const StepInv2 &c, const State5 &s, f2 sc, State5 &k, f2 &acc_c,
                                               Diag2 *dg = nullptr)
@@ -355,22 +380,34 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     k.wy = f2{wzdot, wz};
     k.wf = fma2(Q.neg_rw_Jw, fxtF, c.tqF);                     // :379-382, quirk Q2: tire-frame force in front,
     k.wr = fma2(Q.neg_rw_Jw, fxR, c.tqR);                      //           chassis-frame force at the rear
-    k.xy = fma2(U2, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));     // :384-385 (U cy - V sy, U sy + V cy)
+    if (FIRST) k.xy = s.uv;
+    else k.xy = fma2(U2, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));   // :384-385 (U cd - V sd, U sd + V cd)
 }
 
 // FAST RK4 step (vehicle_model.py:427-445) on pairs; `ok` as in rk4_step.
+// Returns the 1-2-2-1 sum of the stage derivatives in `acc` (x, y already in the global frame): the
+// caller finishes with s += h/6 acc (:438) -- in place when every lane of the wave stayed in range,
+// see StepEngine<float>::advance.
 // DIAG: also state_dot (:440) and the 1-2-2-1 averaged outputs (:441).
-template <bool K2, bool CS, bool DIAG = false>
+// PRE: (sin, cos) of the front steering angle arrive precomputed (LDS-shared control tables hold
+// them per entry; computed by the same sincos_kernel2, so the result is bit for bit the same).
+template <bool K2, bool CS, bool DIAG = false, bool PRE = false>
 __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
                                           const State5 &s, f2 axy, const float delta[4], const float tq[4],
-                                          const float mu[4], float h, State5 &sn, f2 &axy_n,
+                                          const float mu[4], float h, State5 &acc, f2 &axy_n,
                                           State5 *state_dot = nullptr, Diag2 *outputs = nullptr, f2 *FzF_out = nullptr,
-                                          f2 *FzR_out = nullptr)
+                                          f2 *FzR_out = nullptr, f2 steer_sc = f2{0.0f, 1.0f})
 {
     bool ok = true;
     StepInv2 c;
     {
-        const f2 d0 = sincos_steer2(K, delta[0], ok);
+        f2 d0;
+        if (PRE) {
+            d0 = steer_sc;
+            ok = ok && (::fabsf(delta[0]) <= fm::kSincosKernelLimit);
+        } else {
+            d0 = sincos_steer2(K, delta[0], ok);
+        }
         if (K2) {
             c.sdF = f2{d0.x, d0.x}; c.cdF = f2{d0.y, d0.y};
             c.sdR = splat(0.0f); c.cdR = splat(1.0f);
@@ -395,36 +432,49 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
     f2 a, as2;
     const f2 sc0 = sincos_mid2(K, s.wy.y, ok);
     f2 sc;
-    State5 k, acc, st;
+    State5 k, st;
+    float d2, d3, d4;
 
-#define VDYN_S5_EACH(OP) OP(uv) OP(wy) OP(wf) OP(wr) OP(xy)
+    // x, y and yaw feed no derivative (:376-385 read U, V, wz and the wheel speeds only), so the
+    // stages carry the four dynamic pairs; acc.xy accumulates in the frame of the initial yaw.
+#define VDYN_S4_EACH(OP) OP(uv) OP(wy) OP(wf) OP(wr)
+#define VDYN_S5_EACH(OP) VDYN_S4_EACH(OP) OP(xy)
     Diag2 dg, dsum;
 #define VDYN_DG_EACH(OP) OP(fx[0]) OP(fx[1]) OP(fy[0]) OP(fy[1]) OP(s[0]) OP(s[1]) OP(fxt) OP(fyt)
-    planar_deriv2<K2, CS, DIAG>(P, Q, K, c, s, sc0, k, a, &dg);             // K1
+    planar_deriv2<K2, CS, DIAG, true>(P, Q, K, c, s, sc0, k, a, &dg);       // K1
     as2 = a;
     if (DIAG) dsum = dg;
 #define VDYN_S5_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
-    VDYN_S5_EACH(VDYN_S5_1)
-    sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
+    VDYN_S4_EACH(VDYN_S5_1)
+    acc.xy = k.xy;
+    d2 = hh * k.wy.y;
+    sc = stage_rot2(K, d2);
     planar_deriv2<K2, CS, DIAG>(P, Q, K, c, st, sc, k, a, &dg);             // K2
     as2 = fma2(two, a, as2);
 #define VDYN_DG_2(f) dsum.f = fma2(two, dg.f, dsum.f);
     if (DIAG) { VDYN_DG_EACH(VDYN_DG_2) }
 #define VDYN_S5_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
-    VDYN_S5_EACH(VDYN_S5_2)
-    sc = stage_sincos2(K, sc0, hh * k.wy.y, ok);
+    VDYN_S4_EACH(VDYN_S5_2)
+    acc.xy = fma2(two, k.xy, acc.xy);
+    d3 = hh * k.wy.y;
+    sc = stage_rot2(K, d3);
     planar_deriv2<K2, CS, DIAG>(P, Q, K, c, st, sc, k, a, &dg);             // K3
     as2 = fma2(two, a, as2);
     if (DIAG) { VDYN_DG_EACH(VDYN_DG_2) }
 #define VDYN_S5_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
-    VDYN_S5_EACH(VDYN_S5_3)
-    sc = stage_sincos2(K, sc0, h * k.wy.y, ok);
+    VDYN_S4_EACH(VDYN_S5_3)
+    acc.xy = fma2(two, k.xy, acc.xy);
+    d4 = h * k.wy.y;
+    sc = stage_rot2(K, d4);
     planar_deriv2<K2, CS, DIAG>(P, Q, K, c, st, sc, k, a, &dg);             // K4
     as2 = as2 + a;
+    // one range test for the three stage increments
+    ok = ok && (::fmaxf(::fmaxf(::fabsf(d2), ::fabsf(d3)), ::fabsf(d4)) <= kStageYawLimit);
     const float sixth = 1.0f / 6.0f;
-    const f2 h6 = splat(h * sixth);
-#define VDYN_S5_4(f) acc.f = acc.f + k.f; sn.f = fma2(h6, acc.f, s.f);
-    VDYN_S5_EACH(VDYN_S5_4)
+#define VDYN_S5_4(f) acc.f = acc.f + k.f;
+    VDYN_S4_EACH(VDYN_S5_4)
+    acc.xy = acc.xy + k.xy;
+    acc.xy = fma2(f2{acc.xy.x, acc.xy.x}, f2{sc0.y, sc0.x}, pk_hi_conj(acc.xy, sc0));   // into the global frame
     if (DIAG) {
         const f2 sixth2 = splat(sixth);
 #define VDYN_S5_5(f) state_dot->f = acc.f * sixth2;
@@ -441,6 +491,7 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
 #undef VDYN_S5_3
 #undef VDYN_S5_4
 #undef VDYN_S5_EACH
+#undef VDYN_S4_EACH
     axy_n = as2 * splat(sixth);
     return ok;
 }
@@ -454,13 +505,30 @@ namespace vdyn {
 // fp64 has no packed VALU form and goes through rk4_advance.
 template <typename T>
 struct StepEngine {
+    // what a kernel carries from step to step: the 12 persistent scalars of a rollout
+    struct State {
+        T s[10], ax, ay;
+        __device__ __forceinline__ T get(int i) const { return i < 10 ? s[i] : (i == 10 ? ax : ay); }
+        __device__ __forceinline__ void set(int i, T v) { if (i < 10) s[i] = v; else if (i == 10) ax = v; else ay = v; }
+    };
+    template <bool K2, bool CS, bool PRE = false>
+    __device__ __forceinline__ void advance_state(const DevParams<T> &P, State &X, const T delta[4], const T tq[4],
+                                                  const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
+    {
+        rk4_advance<T, K2, false, CS, PRE>(P, X.s, X.ax, X.ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
+    }
     template <bool UNIFORM = true>
     __device__ __forceinline__ void init(const DevParams<T> &) {}
-    template <bool K2, bool CS>
-    __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
-                                            const T tq[4], const T mu[4], T h) const
+    __device__ __forceinline__ void steer_sincos(T d, T &sd, T &cd) const
     {
-        rk4_advance<T, K2, false, CS>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr);
+        bool ok = true;
+        Math<T, false>::sincos(d, &sd, &cd, ok);
+    }
+    template <bool K2, bool CS, bool PRE = false>
+    __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
+                                            const T tq[4], const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
+    {
+        rk4_advance<T, K2, false, CS, PRE>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
     }
     // the same step with state_dot [10] and the averaged outputs [18] (vehicle_model.py:440-441)
     template <bool K2, bool CS>
@@ -481,45 +549,97 @@ struct StepEngine<float> {
         K.init();
         Q.init<UNIFORM>(P);
     }
-    template <bool K2, bool CS>
-    __device__ __forceinline__ void advance(const DevParams<float> &P, float s[10], float &ax, float &ay,
-                                            const float delta[4], const float tq[4], const float mu[4],
-                                            float h) const
+    // (sin, cos) of a steering angle exactly as the FAST step computes it (for control tables
+    // that carry them per entry)
+    __device__ __forceinline__ void steer_sincos(float d, float &sd, float &cd) const
     {
-        State5 S, Sn;
-        S.uv = f2{s[0], s[1]};
-        S.wy = f2{s[2], s[7]};
-        S.wf = f2{s[3], s[4]};
-        S.wr = f2{s[5], s[6]};
-        S.xy = f2{s[8], s[9]};
-        float axn, ayn;
-        f2 axy_n;
-        const bool ok = rk4_step2<K2, CS>(P, Q, K, S, f2{ax, ay}, delta, tq, mu, h, Sn, axy_n);
-        axn = axy_n.x;
-        ayn = axy_n.y;
-        if (__builtin_expect(__any(!ok) != 0, 0)) {
-            if (!ok) {
-                float sn[10];
-                rk4_step<float, K2, false, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
-                Sn.uv = f2{sn[0], sn[1]};
-                Sn.wy = f2{sn[2], sn[7]};
-                Sn.wf = f2{sn[3], sn[4]};
-                Sn.wr = f2{sn[5], sn[6]};
-                Sn.xy = f2{sn[8], sn[9]};
+        const f2 r = sincos_kernel2(K, d);
+        sd = r.x;
+        cd = r.y;
+    }
+    // What a kernel carries from step to step: the ten states as five (even-aligned) register pairs
+    // plus (ax_prev, ay_prev) -- the form the packed step reads and writes, so the time loop neither
+    // unpacks nor re-packs anything.
+    struct State {
+        f2 uv, wy, wf, wr, xy, axy;
+        // rows of the [12][N] layout: U V wz wFL wFR wRL wRR yaw x y ax ay
+        __device__ __forceinline__ float get(int i) const
+        {
+            switch (i) {
+            case 0: return uv.x; case 1: return uv.y; case 2: return wy.x; case 3: return wf.x; case 4: return wf.y;
+            case 5: return wr.x; case 6: return wr.y; case 7: return wy.y; case 8: return xy.x; case 9: return xy.y;
+            case 10: return axy.x; default: return axy.y;
             }
         }
-        s[0] = Sn.uv.x; s[1] = Sn.uv.y; s[2] = Sn.wy.x; s[7] = Sn.wy.y;
-        s[3] = Sn.wf.x; s[4] = Sn.wf.y; s[5] = Sn.wr.x; s[6] = Sn.wr.y;
-        s[8] = Sn.xy.x; s[9] = Sn.xy.y;
-        ax = axn;
-        ay = ayn;
+        __device__ __forceinline__ void set(int i, float v)
+        {
+            switch (i) {
+            case 0: uv.x = v; break; case 1: uv.y = v; break; case 2: wy.x = v; break; case 3: wf.x = v; break;
+            case 4: wf.y = v; break; case 5: wr.x = v; break; case 6: wr.y = v; break; case 7: wy.y = v; break;
+            case 8: xy.x = v; break; case 9: xy.y = v; break; case 10: axy.x = v; break; default: axy.y = v; break;
+            }
+        }
+    };
+    template <bool K2, bool CS, bool PRE = false>
+    __device__ __forceinline__ void advance_state(const DevParams<float> &P, State &X, const float delta[4],
+                                                  const float tq[4], const float mu[4], float h, float sd0 = 0.0f,
+                                                  float cd0 = 1.0f) const
+    {
+        State5 S, A;
+        S.uv = X.uv; S.wy = X.wy; S.wf = X.wf; S.wr = X.wr; S.xy = X.xy;
+        f2 axy_n;
+        const bool ok = rk4_step2<K2, CS, false, PRE>(P, Q, K, S, X.axy, delta, tq, mu, h, A, axy_n, nullptr, nullptr,
+                                                      nullptr, nullptr, f2{sd0, cd0});
+        const f2 h6 = splat(h * (1.0f / 6.0f));
+        // The state is advanced IN PLACE on the normal path: the old state's last use is the very fma that
+        // produces the new one, so no register copy is needed per step.  Only when some lane of the wave
+        // left the FAST range (wave-uniform branch, normally not taken) is the old state kept alive for
+        // that lane's SAFE redo.
+        if (__builtin_expect(__any(!ok) != 0, 0)) {
+            if (!ok) {
+                float s[10], sn[10], axn, ayn;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) s[i] = X.get(i);
+                rk4_step<float, K2, false, true, CS>(P, s, X.axy.x, X.axy.y, delta, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) X.set(i, sn[i]);
+                X.axy = f2{axn, ayn};
+            } else {
+                X.uv = fma2(h6, A.uv, S.uv); X.wy = fma2(h6, A.wy, S.wy); X.wf = fma2(h6, A.wf, S.wf);
+                X.wr = fma2(h6, A.wr, S.wr); X.xy = fma2(h6, A.xy, S.xy);
+                X.axy = axy_n;
+            }
+        } else {
+            X.uv = fma2(h6, A.uv, X.uv);
+            X.wy = fma2(h6, A.wy, X.wy);
+            X.wf = fma2(h6, A.wf, X.wf);
+            X.wr = fma2(h6, A.wr, X.wr);
+            X.xy = fma2(h6, A.xy, X.xy);
+            X.axy = axy_n;
+        }
+    }
+    // the same step on the [10] + 2 scalar form (kernels that read single states between steps)
+    template <bool K2, bool CS, bool PRE = false>
+    __device__ __forceinline__ void advance(const DevParams<float> &P, float s[10], float &ax, float &ay,
+                                            const float delta[4], const float tq[4], const float mu[4],
+                                            float h, float sd0 = 0.0f, float cd0 = 1.0f) const
+    {
+        State X;
+        X.uv = f2{s[0], s[1]}; X.wy = f2{s[2], s[7]}; X.wf = f2{s[3], s[4]}; X.wr = f2{s[5], s[6]};
+        X.xy = f2{s[8], s[9]}; X.axy = f2{ax, ay};
+        advance_state<K2, CS, PRE>(P, X, delta, tq, mu, h, sd0, cd0);
+        s[0] = X.uv.x; s[1] = X.uv.y; s[2] = X.wy.x; s[7] = X.wy.y;
+        s[3] = X.wf.x; s[4] = X.wf.y; s[5] = X.wr.x; s[6] = X.wr.y;
+        s[8] = X.xy.x; s[9] = X.xy.y;
+        ax = X.axy.x;
+        ay = X.axy.y;
     }
     template <bool K2, bool CS>
     __device__ __forceinline__ void advance_diag(const DevParams<float> &P, float s[10], float &ax, float &ay,
                                                  const float delta[4], const float tq[4], const float mu[4],
                                                  float h, float sd[10], Outputs18<float> &o) const
     {
-        State5 S, Sn, D;
+        State5 S, A, D;
         S.uv = f2{s[0], s[1]};
         S.wy = f2{s[2], s[7]};
         S.wf = f2{s[3], s[4]};
@@ -527,11 +647,14 @@ struct StepEngine<float> {
         S.xy = f2{s[8], s[9]};
         Diag2 g;
         f2 axy_n, FzF, FzR;
-        const bool ok = rk4_step2<K2, CS, true>(P, Q, K, S, f2{ax, ay}, delta, tq, mu, h, Sn, axy_n, &D, &g, &FzF, &FzR);
+        const bool ok = rk4_step2<K2, CS, true>(P, Q, K, S, f2{ax, ay}, delta, tq, mu, h, A, axy_n, &D, &g, &FzF, &FzR);
+        const f2 h6 = splat(h * (1.0f / 6.0f));
+        const f2 uv = fma2(h6, A.uv, S.uv), wy = fma2(h6, A.wy, S.wy), wf = fma2(h6, A.wf, S.wf),
+                 wr = fma2(h6, A.wr, S.wr), xy = fma2(h6, A.xy, S.xy);
         float sn[10], axn = axy_n.x, ayn = axy_n.y;
-        sn[0] = Sn.uv.x; sn[1] = Sn.uv.y; sn[2] = Sn.wy.x; sn[7] = Sn.wy.y;
-        sn[3] = Sn.wf.x; sn[4] = Sn.wf.y; sn[5] = Sn.wr.x; sn[6] = Sn.wr.y;
-        sn[8] = Sn.xy.x; sn[9] = Sn.xy.y;
+        sn[0] = uv.x; sn[1] = uv.y; sn[2] = wy.x; sn[7] = wy.y;
+        sn[3] = wf.x; sn[4] = wf.y; sn[5] = wr.x; sn[6] = wr.y;
+        sn[8] = xy.x; sn[9] = xy.y;
         sd[0] = D.uv.x; sd[1] = D.uv.y; sd[2] = D.wy.x; sd[7] = D.wy.y;
         sd[3] = D.wf.x; sd[4] = D.wf.y; sd[5] = D.wr.x; sd[6] = D.wr.y;
         sd[8] = D.xy.x; sd[9] = D.xy.y;
