@@ -374,6 +374,7 @@ def run(args, compute_factory=None):
             "frac": tf / VALU_PEAK_TFLOPS, "traffic": pmc.get("hbm_bytes_per_launch"),
             "flop_per_vehicle_step": FLOP_PER_STEP, "kernel": "rollout_kernel<float,2,LDS-shared>",
             "kernel_ms": kern_s * 1e3, "kernel_ms_median": kern_med * 1e3,
+            "kernel_ms_percentiles": {str(q): float(np.percentile(durs, q)) * 1e3 for q in (0, 10, 50, 90, 99, 100)},
             "kernel_steps_per_s": steps_per_launch / kern_s,
             "note": "register-resident scalar-nonlinear kernel: MFMA has no contraction to work on and HBM "
                     "carries 0.48 B per vehicle-step (roofline_hbm); VALU issue binds",

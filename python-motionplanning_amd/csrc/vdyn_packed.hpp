@@ -56,7 +56,7 @@ __device__ __forceinline__ f2 pk_hi_conj(f2 a, f2 b)      // (-a.y b.x, a.y b.y)
 // Coefficients and other constants as (c, c) pairs, made opaque to the optimiser so that they are
 // materialised once and stay in VGPRs instead of being rebuilt at every use.
 struct PkConsts {
-    f2 at[8];            // atan: c8 .. c1 (vdyn_fastmath.hpp, atan_rcp)
+    f2 at[8];            // atan(t) = t Q(t^2) on [0, 1]: q7 .. q0 (tools/fit_polys.py, degree 7: 2.3e-7 relative)
     f2 sn[4];            // sin on [-pi/2, pi/2]: the four coefficients of sin_mid / sin_0_pi
     f2 pi_hi, pi_lo, inv_pi, pio2;
     f2 big, neg2, tiny;  // 2^100 (indicator scale), -2, 1e-30 (floor of s^2, quirk Q5)
@@ -64,6 +64,7 @@ struct PkConsts {
     f2 sck[3];           // (sin, cos) kernel coefficients on |r| <= pi/4 (sincos_kernel), one pair per degree
     f2 cs[5];            // cos(z) = Q(z^2) on |z| <= pi/2, highest degree first (CS: sin(y) = cos(y - pi/2), y in [0, pi])
     f2 rot_a, rot_b, rot_c;   // (-1/6, 1/24), (1, -1/2), (0, 1): (sin d, cos d) of a stage's small yaw increment
+    f2 scp[4];           // (sin, cos) on |r| <= pi/2 in one chain: (sn[i], cs[i]) pairs (sincos_mid2)
 
     __device__ __forceinline__ void pin(f2 &v, float c)
     {
@@ -72,8 +73,8 @@ struct PkConsts {
     }
     __device__ __forceinline__ void init()
     {
-        const float a[8] = {2.872858429e-03f, -1.616817340e-02f, 4.286647215e-02f, -7.520283014e-02f,
-                            1.064901948e-01f, -1.420586258e-01f, 1.999291778e-01f, -3.333308995e-01f};
+        const float a[8] = {-4.729942884e-03f, 2.439327165e-02f, -5.969851837e-02f, 9.930104017e-02f,
+                            -1.402552277e-01f, 1.997082233e-01f, -3.333206475e-01f, 9.999998808e-01f};
         const float s[4] = {2.607052693e-06f, -1.981028618e-04f, 8.333077654e-03f, -1.666665971e-01f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) pin(at[i], a[i]);
@@ -100,6 +101,11 @@ struct PkConsts {
         const float cc[5] = {2.312937249e-05f, -1.385257230e-03f, 4.166342318e-02f, -4.999989867e-01f, 9.999999404e-01f};
 #pragma unroll
         for (int i = 0; i < 5; ++i) pin(cs[i], cc[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            scp[i] = f2{s[i], cc[i]};
+            asm volatile("" : "+v"(scp[i]));
+        }
         rot_a = f2{-1.0f / 6.0f, 1.0f / 24.0f};
         rot_b = f2{1.0f, -0.5f};
         rot_c = f2{0.0f, 1.0f};
@@ -110,7 +116,9 @@ struct PkConsts {
 // Vehicle constants as pairs (front axle pair F = (FL, FR), rear pair R = (RL, RR)).
 struct PkParams {
     f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw;
-    f2 ab_F, ab_R;                                       // (+a, +a), (-b, -b): lever arms of the pairs
+    f2 kapF, kapR;                                       // (2 - C) pi/2 per wheel (phase of the x > 1 branch, sin_c_atan2x2)
+    f2 ab_F, ab_R;                                       // (+a, +a) / Izz, (-b, -b) / Izz: lever arms of the pairs
+    float hT_Izz;                                        // (T/2) / Izz
     f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
     f2 neg_rw_Jw;                                        // -rw / Jw
     f2 Fz0F, Fz0R, dfxF, dfyF, dfxR, dfyR;               // static loads and load-transfer coefficients per pair (:255-258)
@@ -122,19 +130,25 @@ struct PkParams {
         BF = f2{P.B[0], P.B[1]}; BR = f2{P.B[2], P.B[3]};
         invBF = f2{P.invB[0], P.invB[1]}; invBR = f2{P.invB[2], P.invB[3]};
         CF = f2{P.C[0], P.C[1]}; CR = f2{P.C[2], P.C[3]};
+        {
+            const float hp = 1.57079637050628662109375f;
+            kapF = f2{(2.0f - P.C[0]) * hp, (2.0f - P.C[1]) * hp};
+            kapR = f2{(2.0f - P.C[2]) * hp, (2.0f - P.C[3]) * hp};
+        }
         // Scalars first, each behind a zero-instruction barrier: left visible as neighbouring struct
         // fields, pairs of them are fetched with one 8-byte read, and because such reads overlap
         // (inv_Jw|a, a|b) the compiler then parks that part of the by-value struct in scratch.
         float a = P.a, b = P.b, iJw = P.inv_Jw, dxl = P.DfzxL, dxr = P.DfzxR, dyf = P.DfzyF, dyr = P.DfzyR,
-              r_w = P.rw, f0f = P.Fz0F, f0r = P.Fz0R, hT = P.half_T, im = P.inv_m;
+              r_w = P.rw, f0f = P.Fz0F, f0r = P.Fz0R, hT = P.half_T, im = P.inv_m, iIz = P.inv_Izz;
         if (UNIFORM)   // stay in SGPRs: a scalar source operand costs the packed op no VGPR read port
             asm("" : "+s"(a), "+s"(b), "+s"(iJw), "+s"(dxl), "+s"(dxr), "+s"(dyf), "+s"(dyr), "+s"(r_w), "+s"(f0f),
-                "+s"(f0r), "+s"(hT), "+s"(im));
+                "+s"(f0r), "+s"(hT), "+s"(im), "+s"(iIz));
         else
             asm("" : "+v"(a), "+v"(b), "+v"(iJw), "+v"(dxl), "+v"(dxr), "+v"(dyf), "+v"(dyr), "+v"(r_w), "+v"(f0f),
-                "+v"(f0r), "+v"(hT), "+v"(im));
+                "+v"(f0r), "+v"(hT), "+v"(im), "+v"(iIz));
         rw = splat(r_w); inv_Jw = splat(iJw);
-        ab_F = splat(a); ab_R = splat(-b);
+        ab_F = splat(a * iIz); ab_R = splat(-b * iIz);
+        hT_Izz = hT * iIz;
         a_negb = f2{a, -b};
         hT_side = f2{-hT, hT};
         inv_m = splat(im);
@@ -154,9 +168,10 @@ struct PkParams {
 #define VDYN_BOTH(q) _Pragma("unroll") for (int q = 0; q < 2; ++q)
 
 // sin(C atan(x)) for both pairs; inv_x = 1/x per half.
+// kappa = (2 - C) pi/2 per half (CS only).
 template <bool CS>
-__device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], const f2 x[2], const f2 inv_x[2],
-                                              f2 out[2])
+__device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], const f2 kappa[2], const f2 x[2],
+                                              const f2 inv_x[2], f2 out[2])
 {
     // atan_rcp on all four halves: selects scalar, Horner chain packed
     bool b0[2], b1[2];
@@ -174,13 +189,8 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
     VDYN_BOTH(q) p[q] = K.at[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) VDYN_BOTH(q) p[q] = fma2(p[q], u[q], K.at[i]);
-    VDYN_BOTH(q) p[q] = p[q] * u[q];
-    VDYN_BOTH(q) p[q] = fma2(p[q], t[q], t[q]);
-    if (CS) {
-        f2 d[2];
-        VDYN_BOTH(q) d[q] = fma2(K.neg2, p[q], K.pio2);
-        VDYN_BOTH(q) th[q] = fma2(ind[q], d[q], p[q]);
-    } else {
+    VDYN_BOTH(q) p[q] = p[q] * t[q];
+    if (!CS) {
         const float pio2 = 1.57079637050628662109375f;
         VDYN_BOTH(q) th[q] = f2{b0[q] ? (::copysignf(pio2, x[q].x) - p[q].x) : p[q].x,
                                b1[q] ? (::copysignf(pio2, x[q].y) - p[q].y) : p[q].y};
@@ -190,13 +200,16 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
         // |z| <= pi/2 -- no reflection, no min, and z comes out of the fma that forms y.  Absolute
         // accuracy 1.8e-7 (the reflected odd polynomial was 2 ulp relative): the force it scales,
         // s_x mu Fz / s, inherits an absolute error of 2e-7 Fz ~ 1e-3 N per tire.
-        f2 z[2], q4[2];
-        VDYN_BOTH(q) z[q] = fma2(C[q], th[q], -K.pio2);
+        // theta = p (x <= 1) or pi/2 - p (x > 1), and cos is even: cos(C theta - pi/2) = cos(C p - phi) with
+        // phi = pi/2 or (C - 1) pi/2 = pi/2 - [x > 1] (2 - C) pi/2
+        f2 z[2], q4[2], phi[2];
+        VDYN_BOTH(q) phi[q] = fma2(ind[q], -kappa[q], K.pio2);
+        VDYN_BOTH(q) z[q] = fma2(C[q], p[q], -phi[q]);
         VDYN_BOTH(q) w[q] = z[q] * z[q];
         VDYN_BOTH(q) q4[q] = fma2(K.cs[0], w[q], K.cs[1]);
         VDYN_BOTH(q) q4[q] = fma2(q4[q], w[q], K.cs[2]);
         VDYN_BOTH(q) q4[q] = fma2(q4[q], w[q], K.cs[3]);
-        VDYN_BOTH(q) out[q] = fma2(q4[q], w[q], K.cs[4]);
+            VDYN_BOTH(q) out[q] = fma2(q4[q], w[q], K.cs[4]);
         return;
     }
     VDYN_BOTH(q) y[q] = C[q] * th[q];
@@ -222,10 +235,14 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
 
 // All four tires (vehicle_model.py:274-373, as tire_force in vdyn_device.hpp): index 0 = front
 // pair (always steered), index 1 = rear pair (steered only with k = 12 controls).
-template <bool REAR_STEERED, bool CS>
-__device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], const f2 invB[2], const f2 C[2], f2 rw,
-                                              f2 vxc, const f2 vyc[2], const f2 w[2], const f2 cd[2], const f2 sd[2],
-                                              const f2 muFz[2], f2 fx[2], f2 fy[2], f2 fxt[2], f2 fyt[2], f2 s[2])
+// CS (B >= 0): the slips are carried pre-multiplied by B -- x = B s comes out of the same rsq that
+// normalises the slip, 1/x is that rsq itself, and B cancels in s_x mu / s = (B s_x) sin(C atan x) / x.
+// s[] (DIAG only) is the combined slip itself.
+template <bool REAR_STEERED, bool CS, bool DIAG>
+__device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], const f2 invB[2], const f2 C[2],
+                                              const f2 kappa[2], f2 rw, f2 vxc, const f2 vyc[2], const f2 w[2],
+                                              const f2 cd[2], const f2 sd[2], const f2 muFz[2], f2 fx[2], f2 fy[2],
+                                              f2 fxt[2], f2 fyt[2], f2 s[2])
 {
     f2 vx[2], vy[2], rvx[2], sx[2], sy[2], s2[2], rs[2], xs[2], ix[2], g[2], tmp[2];
     tmp[0] = vyc[0] * sd[0];
@@ -242,6 +259,7 @@ __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], 
         vy[1] = vyc[1];
     }
     VDYN_BOTH(q) rvx[q] = f2{fm::rcp(vx[q].x), fm::rcp(vx[q].y)};
+    if (CS) VDYN_BOTH(q) rvx[q] = rvx[q] * B[q];                                                   // B / vx
     VDYN_BOTH(q) sx[q] = fma2(rw, w[q], -vx[q]);
     VDYN_BOTH(q) sx[q] = sx[q] * rvx[q];
     VDYN_BOTH(q) sy[q] = f2{-vy[q].x * ::fabsf(rvx[q].x), -vy[q].y * ::fabsf(rvx[q].y)};          // quirk Q4
@@ -251,10 +269,16 @@ __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], 
     VDYN_BOTH(q) s2[q] = fma2(sy[q], sy[q], K.tiny);
     VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);
     VDYN_BOTH(q) rs[q] = f2{fm::rsq(s2[q].x), fm::rsq(s2[q].y)};
-    VDYN_BOTH(q) s[q] = s2[q] * rs[q];
-    VDYN_BOTH(q) xs[q] = B[q] * s[q];
-    VDYN_BOTH(q) ix[q] = rs[q] * invB[q];
-    sin_c_atan2x2<CS>(K, C, xs, ix, g);
+    if (CS) {
+        VDYN_BOTH(q) xs[q] = s2[q] * rs[q];                     // x = B s
+        sin_c_atan2x2<CS>(K, C, kappa, xs, rs, g);
+        if (DIAG) VDYN_BOTH(q) s[q] = xs[q] * invB[q];
+    } else {
+        VDYN_BOTH(q) s[q] = s2[q] * rs[q];
+        VDYN_BOTH(q) xs[q] = B[q] * s[q];
+        VDYN_BOTH(q) ix[q] = rs[q] * invB[q];
+        sin_c_atan2x2<CS>(K, C, kappa, xs, ix, g);
+    }
     VDYN_BOTH(q) g[q] = g[q] * rs[q];
     VDYN_BOTH(q) g[q] = g[q] * muFz[q];
     VDYN_BOTH(q) fxt[q] = sx[q] * g[q];
@@ -287,20 +311,24 @@ __device__ __forceinline__ f2 sincos_kernel2(const PkConsts &K, float r)
     return fma2(a, p, f2{r, ::fmaf(-0.5f, u, 1.0f)});
 }
 
-// (sin x, cos x) for |x| <= fm::kSincosMidLimit (yaw is never wrapped, quirk Q7): sincos_mid.
+// (sin x, cos x) for |x| <= fm::kSincosMidLimit (yaw is never wrapped, quirk Q7): x = k pi + r with
+// |r| <= pi/2 (two-term Cody-Waite: the neglected tail of pi is 3e-15 k), sin r as the odd and cos r as
+// the even polynomial in ONE packed Horner chain, both signs flipped for odd k.  No quadrant swap.
+// sin: 1.1e-7 relative; cos: 1.8e-7 absolute (it multiplies velocities of tens of m/s: 5e-6 m/s).
 __device__ __forceinline__ f2 sincos_mid2(const PkConsts &K, float x, bool &ok)
 {
-    const float k = __builtin_rintf(x * 0.636619772367581343076f);
-    float r = ::fmaf(-k, 1.57079637050628662109375f, x);
-    r = ::fmaf(-k, -4.37113900018624283e-08f, r);
-    r = ::fmaf(-k, -1.7151245100059e-15f, r);
-    const f2 sc = sincos_kernel2(K, r);
-    const int q = (int)k;
-    const bool swap = (q & 1) != 0;
-    const float s0 = swap ? sc.y : sc.x, c0 = swap ? sc.x : sc.y;
-    const unsigned fs = ((unsigned)(q & 2)) << 30, fc = ((unsigned)((q + 1) & 2)) << 30;
+    const float k = __builtin_rintf(x * 0.318309886183790671538f);
+    float r = ::fmaf(-k, 3.1415927410125732421875f, x);
+    r = ::fmaf(-k, -8.74227800037248566e-08f, r);
+    const float u = r * r;
+    const f2 u2 = f2{u, u};
+    f2 p = fma2(K.scp[0], u2, K.scp[1]);
+    p = fma2(p, u2, K.scp[2]);
+    p = fma2(p, u2, K.scp[3]);                                  // (S(u), c0 + c1 u + c2 u^2 + c3 u^3 -> times u + c4 below)
+    const f2 sc = fma2(f2{r * u, u}, p, f2{r, K.cs[4].x});      // (r + r u S, 1 + u (...))
+    const unsigned flip = ((unsigned)(int)k) << 31;
     ok = ok && (::fabsf(x) <= fm::kSincosMidLimit);
-    return f2{__uint_as_float(__float_as_uint(s0) ^ fs), __uint_as_float(__float_as_uint(c0) ^ fc)};
+    return f2{__uint_as_float(__float_as_uint(sc.x) ^ flip), __uint_as_float(__float_as_uint(sc.y) ^ flip)};
 }
 
 // (sin, cos) of a steering angle: no reduction inside |delta| <= pi/4 (every physical steering
@@ -348,18 +376,18 @@ struct Diag2 {
 // R(yaw0) sum_j w_j R(d_j) u_j == sum_j w_j R(yaw0 + d_j) u_j).  FIRST: the first stage, d = 0.
 template <bool K2, bool CS, bool DIAG = false, bool FIRST = false>
 __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
-                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, f2 &acc_c,
+                                              const StepInv2 &c, const State5 &s, f2 sc, State5 &k, f2 &sums_out,
                                               Diag2 *dg = nullptr)
 {
     const float U = s.uv.x, V = s.uv.y, wz = s.wy.x;
     const f2 U2 = f2{U, U}, V2 = f2{V, V}, wz2 = f2{wz, wz};
     const f2 vxc = fma2(Q.hT_side, wz2, U2);                  // :261-271 (left, right), both axles (quirk Q8)
     const f2 vyb = fma2(Q.a_negb, wz2, V2);                   // (V + a wz, V - b wz): front, rear
-    const f2 Bq[2] = {Q.BF, Q.BR}, iBq[2] = {Q.invBF, Q.invBR}, Cq[2] = {Q.CF, Q.CR};
+    const f2 Bq[2] = {Q.BF, Q.BR}, iBq[2] = {Q.invBF, Q.invBR}, Cq[2] = {Q.CF, Q.CR}, kq[2] = {Q.kapF, Q.kapR};
     const f2 vyq[2] = {f2{vyb.x, vyb.x}, f2{vyb.y, vyb.y}}, wq[2] = {s.wf, s.wr};
     const f2 cdq[2] = {c.cdF, c.cdR}, sdq[2] = {c.sdF, c.sdR}, mfq[2] = {c.muFzF, c.muFzR};
     f2 fxq[2], fyq[2], fxtq[2], fytq[2], slq[2];
-    tire_force2x2<!K2, CS>(K, Bq, iBq, Cq, Q.rw, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq, slq);
+    tire_force2x2<!K2, CS, DIAG>(K, Bq, iBq, Cq, kq, Q.rw, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq, slq);
     if (DIAG) {
         dg->fx[0] = fxq[0]; dg->fx[1] = fxq[1];
         dg->fy[0] = fyq[0]; dg->fy[1] = fyq[1];
@@ -374,9 +402,11 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     const f2 sums = f2{sumx, sumy};                            // (sum Fx, sum Fy)
     const f2 cross = pk_cross(s.uv, s.wy);                     // (V wz, -U wz)
     k.uv = fma2(Q.inv_m, sums, cross);                         // (U_dot, V_dot)
-    acc_c = k.uv - cross;                                      // :413-414 (axc, ayc)
-    const f2 my = fma2(fyF, Q.ab_F, fyR * Q.ab_R);             // a fy_front - b fy_rear, per side
-    const float wzdot = P.inv_Izz * ((my.x + my.y) + P.half_T * (sfx.y - sfx.x));
+    // :413-414: axc = U_dot - V wz, ayc = V_dot + U wz are the force sums over m; only their 1-2-2-1
+    // average is ever used (:442-443), so the caller accumulates the sums and scales once
+    sums_out = sums;
+    const f2 my = fma2(fyF, Q.ab_F, fyR * Q.ab_R);             // (a fy_front - b fy_rear) / Izz, per side
+    const float wzdot = (my.x + my.y) + Q.hT_Izz * (sfx.y - sfx.x);
     k.wy = f2{wzdot, wz};
     k.wf = fma2(Q.neg_rw_Jw, fxtF, c.tqF);                     // :379-382, quirk Q2: tire-frame force in front,
     k.wr = fma2(Q.neg_rw_Jw, fxR, c.tqR);                      //           chassis-frame force at the rear
@@ -492,7 +522,7 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
 #undef VDYN_S5_4
 #undef VDYN_S5_EACH
 #undef VDYN_S4_EACH
-    axy_n = as2 * splat(sixth);
+    axy_n = as2 * (Q.inv_m * splat(sixth));                  // wave-uniform factor: hoisted out of the time loop
     return ok;
 }
 
