@@ -65,6 +65,7 @@ def parse(argv=None):
                          "(hipMemcpyPeerAsync into every peer's slot on a copy stream: no CU-resident copy kernel)")
     ap.add_argument("--rollouts-per-gpu", type=int, default=N_PER_GPU, help=argparse.SUPPRESS)
     ap.add_argument("--horizon", type=int, default=HORIZON, help=argparse.SUPPRESS)
+    ap.add_argument("--dump-durations", action="store_true", help="put every timed launch's kernel duration (ms) in the JSON")
     ap.add_argument("--dump-gathered", default=None, help=argparse.SUPPRESS)   # tests: every rank saves what it holds
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 code path (RCCL all-gather of terminal states, overlapped with the "
@@ -270,14 +271,8 @@ def run(args, compute_factory=None):
     del s0_all, pid_all
     xch = D.make_exchange(args.exchange, sh, rows=12, like=s0) if collective else None
 
-    kern_ev = []
-
-    def step(record):
-        if record:
-            a = cp.mark()
+    def step():
         term = cp.rollout(s0, tabd, pid)
-        if record:
-            kern_ev.append((a, cp.mark()))
         if collective:
             # the exchange step of BASELINE configs[3]: every rank ends up with all terminal states
             # (rank-major blocks [world][12][n_pad]).  It runs beside the compute stream; the previous
@@ -295,6 +290,14 @@ def run(args, compute_factory=None):
             dist.barrier()
         cp.sync()
 
+    # A full Python garbage collection (tens of ms once torch's ~1e6 objects are alive) landing inside the
+    # timed loop stalls the launch queue: measured 0.24 -> 0.26-0.34 ms per step on the runs it hit.  The
+    # cyclic collector is paused from here to the end of the timed steps (reference counting still frees
+    # tensors).  It runs BEFORE the clock ramp: the collection itself leaves the GPU idle for ~50 ms, after
+    # which the first ~90 launches ran up to 20 % slow.
+    import gc
+    gc.collect()
+    gc.disable()
     # clock ramp (reported in the JSON as `prewarm`): the same step, untimed, for a fixed wall time
     prewarm_launches = 0
     t_pre = time.perf_counter()
@@ -303,21 +306,27 @@ def run(args, compute_factory=None):
             cp.rollout(s0, tabd, pid)              # kernel only: a wall-time loop must not contain a collective
         prewarm_launches += 16                     # (ranks would issue different numbers of them)
         cp.sync()
-    # A full Python garbage collection (tens of ms once torch's ~1e6 objects are alive) landing inside the
-    # timed loop stalls the launch queue: measured 0.24 -> 0.26-0.34 ms per step on the runs it hit.  The
-    # cyclic collector is paused for the warm-up and timed steps (reference counting still frees tensors).
-    import gc
-    gc.collect()
-    gc.disable()
     for _ in range(args.warmup):
-        step(False)
+        step()
     fence()
+    # ONE pair of HIP events brackets the K timed steps on the launching stream (an event pair per launch
+    # costs ~3 % of a 0.2 ms step: the markers serialise the dispatches)
     t0 = time.perf_counter()
+    ev_a = cp.mark()
     for _ in range(args.steps):
-        term = step(True)
+        term = step()
+    ev_b = cp.mark()
     enqueue = time.perf_counter() - t0     # host time to queue the K steps (GPU-bound when << elapsed)
     fence()
     elapsed = time.perf_counter() - t0
+    region_s = cp.elapsed_s(ev_a, ev_b)
+    # per-launch durations, sampled right after the timed region (same clock state), kernel only
+    kern_ev = []
+    for _ in range(min(max(args.steps, 20), 100)):
+        a = cp.mark()
+        cp.rollout(s0, tabd, pid)
+        kern_ev.append((a, cp.mark()))
+    cp.sync()
     gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -334,8 +343,11 @@ def run(args, compute_factory=None):
         if args.dump_gathered:
             np.save(os.path.join(args.dump_gathered, f"gathered_rank{rank}.npy"), full.cpu().numpy())
 
-    durs = np.array([cp.elapsed_s(a, b) for a, b in kern_ev]) if kern_ev else np.array([float("nan")])
-    kern_s, kern_med = float(durs.mean()), float(np.median(durs))
+    durs = np.array([cp.elapsed_s(a, b) for a, b in kern_ev])
+    kern_iso, kern_med = float(durs.mean()), float(np.median(durs))
+    # the dominant kernel's average launch duration over the timed region (launch-to-launch, dispatch gaps
+    # included); with an exchange inside the step the isolated sample is the kernel's own time
+    kern_s = kern_iso if collective else region_s / args.steps
     units = n_total * H * args.steps
     steps_per_launch = n_local * H
     out = {
@@ -373,12 +385,16 @@ def run(args, compute_factory=None):
             "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / VALU_PEAK_TFLOPS, "traffic": pmc.get("hbm_bytes_per_launch"),
             "flop_per_vehicle_step": FLOP_PER_STEP, "kernel": "rollout_kernel<float,2,LDS-shared>",
-            "kernel_ms": kern_s * 1e3, "kernel_ms_median": kern_med * 1e3,
+            "kernel_ms": kern_s * 1e3, "kernel_ms_source": "isolated per-launch events after the timed region" if collective
+            else "one HIP event pair around the K timed launches / K",
+            "kernel_ms_isolated_mean": kern_iso * 1e3, "kernel_ms_median": kern_med * 1e3,
             "kernel_ms_percentiles": {str(q): float(np.percentile(durs, q)) * 1e3 for q in (0, 10, 50, 90, 99, 100)},
             "kernel_steps_per_s": steps_per_launch / kern_s,
             "note": "register-resident scalar-nonlinear kernel: MFMA has no contraction to work on and HBM "
                     "carries 0.48 B per vehicle-step (roofline_hbm); VALU issue binds",
         }
+        if args.dump_durations:
+            out["roofline"]["kernel_ms_all"] = [round(float(x) * 1e3, 4) for x in durs]
         ipw = pmc.get("valu_insts_per_wave_per_rk4_step")
         if ipw:
             # issue-slot form of the same roofline: measured VALU wave-instructions per RK4 step
