@@ -24,6 +24,8 @@ struct VdynHandle {
     size_t d_fleet_bytes = 0;
     void *d_aux = nullptr;          // controllers' auxiliary waypoint tables (segment lengths, bounding circles)
     size_t d_aux_bytes = 0;
+    void *d_cand = nullptr;         // MPC candidate table with the steering angles' (sin, cos) per entry
+    size_t d_cand_bytes = 0;
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -163,6 +165,7 @@ void vdyn_destroy(VdynHandle *h)
     if (h->h_mapped) (void)hipHostFree(h->h_mapped);
     if (h->d_fleet) (void)hipFree(h->d_fleet);
     if (h->d_aux) (void)hipFree(h->d_aux);
+    if (h->d_cand) (void)hipFree(h->d_cand);
     delete h;
 }
 
@@ -279,8 +282,20 @@ int mpc_dev(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, con
     if (!ego || !goal || !best_cost || !best_idx || (H > 0 && !cand))
         return h->fail(VDYN_ERR_ARG, "mpc_argmin: null buffer");
     VDYN_HIP(h, hipSetDevice(h->device));
+    // candidate table with (sin, cos) of the steering angles: handle-owned scratch, grown on demand
+    // (hipFree waits for launches still reading the old one)
+    const size_t c4 = sizeof(T) * 4 * (size_t)H * (size_t)C;
+    if (c4 > h->d_cand_bytes) {
+        if (h->d_cand) { (void)hipFree(h->d_cand); h->d_cand = nullptr; h->d_cand_bytes = 0; }
+        if (hipMalloc(&h->d_cand, c4) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_cand = nullptr;
+            return h->fail(VDYN_ERR_OOM, "mpc_argmin: candidate table allocation failed");
+        }
+        h->d_cand_bytes = c4;
+    }
     VDYN_HIP(h, vdyn::launch_mpc_argmin<T>(h->p, E, C, H, ego, cand, goal, dt, w_delta, best_cost,
-                                           best_idx, cost_all, (hipStream_t)stream));
+                                           best_idx, cost_all, static_cast<T *>(h->d_cand), (hipStream_t)stream));
     return VDYN_OK;
 }
 

@@ -404,10 +404,30 @@ planar_model_kernel(DevParams<T> P, int64_t n, const T *__restrict__ state, cons
 template <typename T> constexpr int mpc_block_max() { return sizeof(T) == 4 ? 512 : 256; }
 template <typename T> constexpr int mpc_waves_per_simd() { return sizeof(T) == 4 ? 2 : 1; }
 
+// Candidate table for the selection kernel: cand [H][2][C] -> cand4 [H][C][4] = (delta, torque, sin delta,
+// cos delta).  The candidates are shared by all E egos, so the steering angle's (sin, cos) is evaluated
+// once per table entry here instead of E times in the selection kernel, by the function the step itself
+// would call (bit-identical results); a lane then reads its step's controls as one 16-byte load.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+mpc_prepare_kernel(DevParams<T> P, int C, int H, const T *__restrict__ cand, T *__restrict__ cand4)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;    // = t * C + c
+    StepEngine<T> eng;
+    eng.init(P);
+    if (i >= (int64_t)H * C) return;
+    const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
+    const T d = cand[((int64_t)t * 2) * C + c], tq = cand[((int64_t)t * 2 + 1) * C + c];
+    T sd, cd;
+    eng.steer_sincos(d, sd, cd);
+    T *o = cand4 + i * 4;
+    o[0] = d; o[1] = tq; o[2] = sd; o[3] = cd;
+}
+
 template <typename T, bool CS>
 __global__ void __launch_bounds__(mpc_block_max<T>(), mpc_waves_per_simd<T>())
 mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego,
-                  const T *__restrict__ cand, const T *__restrict__ goal, T h, T w_delta,
+                  const T *__restrict__ cand4, const T *__restrict__ goal, T h, T w_delta,
                   T *__restrict__ best_cost, int *__restrict__ best_idx, T *__restrict__ cost_all)
 {
     __shared__ T s_cost[16];
@@ -416,10 +436,9 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
     const T inf = T(INFINITY);
     constexpr int kNone = 0x7fffffff;
 
-    T s0[10];
+    typename StepEngine<T>::State X0;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) s0[i] = ego[(int64_t)i * E + e];
-    const T ax0 = ego[(int64_t)10 * E + e], ay0 = ego[(int64_t)11 * E + e];
+    for (int i = 0; i < 12; ++i) X0.set(i, ego[(int64_t)i * E + e]);
     const T gx = goal[e], gy = goal[(int64_t)E + e];
 
     T bc = inf;
@@ -427,19 +446,18 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
     StepEngine<T> eng;
     eng.init(P);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        T s[10], ax = ax0, ay = ay0, dsum = T(0);
-#pragma unroll
-        for (int i = 0; i < 10; ++i) s[i] = s0[i];
+        typename StepEngine<T>::State X = X0;
+        T dsum = T(0);
         Ctrl<T, 2> cc;                         // step t + 1's controls are fetched behind step t (see rollout_kernel)
-        if (H > 0) cc.set(P, cand + c, C);
+        if (H > 0) cc.set_pre(P, cand4 + (int64_t)c * 4);
         for (int t = 0; t < H; ++t) {
             Ctrl<T, 2> cn;
-            cn.set(P, cand + ((int64_t)min(t + 1, H - 1) * 2) * C + c, C);
-            eng.template advance<true, CS>(P, s, ax, ay, cc.delta, cc.tq, cc.mu, h);
+            cn.set_pre(P, cand4 + ((int64_t)min(t + 1, H - 1) * C + c) * 4);
+            eng.template advance_state<true, CS, true>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
             cc = cn;
         }
-        const T dx = s[8] - gx, dy = s[9] - gy;
+        const T dx = X.get(8) - gx, dy = X.get(9) - gy;
         const T cost = sqrt_t(dx * dx + dy * dy) + w_delta * dsum;
         if (cost_all != nullptr) cost_all[(int64_t)e * C + c] = cost;
         if (cost < bc) { bc = cost; bi = c; }  // strict '<': lowest index wins ties; NaN/inf never win
@@ -1131,18 +1149,25 @@ hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, c
 template <typename T>
 hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *ego, const T *cand,
                              const T *goal, double dt, double w_delta, T *best_cost, int *best_idx,
-                             T *cost_all, hipStream_t st)
+                             T *cost_all, T *cand4, hipStream_t st)
 {
     if (E <= 0) return hipSuccess;
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
+    if (H > 0) {
+        const int64_t n = (int64_t)H * C;
+        hipLaunchKernelGGL((mpc_prepare_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, P,
+                           C, H, cand, cand4);
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return e_;
+    }
     int block = ((C + 63) / 64) * 64;
     block = std::max(64, std::min(block, mpc_block_max<T>()));
     if (shape_factors_small(p))
         hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
-                           C, H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+                           C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
     else
         hipLaunchKernelGGL((mpc_argmin_kernel<T, false>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
-                           C, H, ego, cand, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+                           C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
     return hipGetLastError();
 }
 
@@ -1288,7 +1313,7 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
                                                const T *, T *, T *, T *, T *, hipStream_t);          \
     template hipError_t launch_mpc_argmin<T>(const VdynParams &, int, int, int, const T *, const T *, \
-                                             const T *, double, double, T *, int *, T *, hipStream_t); \
+                                             const T *, double, double, T *, int *, T *, T *, hipStream_t); \
     template hipError_t launch_closed_loop<T>(const VdynParams &, const VdynCtrlGains &,             \
                                               const ClosedLoopArgs<T> &, hipStream_t);               \
     template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t); \
