@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--wheel-parallel", action="store_true",
                     help="four lanes per rollout (shorter serial chain for small shards; agrees with the "
                          "lane-per-rollout kernel to rounding, not bit for bit): the labelled second number of --strong")
-    ap.add_argument("--exchange", choices=("rccl",), default="rccl",
+    ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl",
                     help="N>1 exchange of terminal states: RCCL all-gather (default) or direct peer copies "
                          "(hipMemcpyPeerAsync into every peer's slot on a copy stream: no CU-resident copy kernel)")
     ap.add_argument("--rollouts-per-gpu", type=int, default=N_PER_GPU, help=argparse.SUPPRESS)
@@ -216,6 +216,9 @@ class HipCompute:
     def rollout(self, s0, tab, pid):
         return self.vm.rollout(s0, tab, path_id=pid)
 
+    def handle(self):
+        return self.vm.handle()
+
     def sync(self):
         self.torch.cuda.synchronize()
 
@@ -269,7 +272,7 @@ def run(args, compute_factory=None):
     pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
     del s0_all, pid_all
-    xch = D.make_exchange(args.exchange, sh, rows=12, like=s0) if collective else None
+    xch = D.make_exchange(args.exchange, sh, rows=12, like=s0, handle=cp.handle()) if collective else None
 
     def step():
         term = cp.rollout(s0, tabd, pid)

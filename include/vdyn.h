@@ -365,6 +365,33 @@ int vdyn_interpolate_waypoints_f32_host(VdynHandle *h, int32_t E, int32_t P, int
                                         const int32_t *best_idx, double res, int32_t Wmax, float *wp_out,
                                         int32_t *wcount);
 
+/* ==== multi-GPU exchange of terminal blocks without a collective kernel ====================
+ * The path's only exchange step (north_star: "all-gather ... of final trajectories only") moves one
+ * small block per rank ([12][n_local] fp32: 393 KB at 8192 rollouts, 3.1 MB at 65536).  RCCL does it
+ * with a copy kernel that shares the CUs with the next rollout.  These entry points do it with
+ * copies instead: every rank owns a slot buffer [world][block], exports it once (hipIpcGetMemHandle),
+ * opens its peers' buffers (hipIpcOpenMemHandle) and, per step, pushes its block into slot `rank`
+ * of every buffer with hipMemcpyAsync on the handle's own copy stream, ordered behind the compute
+ * stream by an event.  One process per GPU; the 64-byte handles travel through whatever side
+ * channel the caller has (torch.distributed.all_gather_object in distributed.PeerExchange).
+ * There is no counterpart in the reference (its only parallelism is the process pool of
+ * local_planner.py:369-374).                                                                    */
+typedef struct VdynIpcHandle { unsigned char bytes[64]; } VdynIpcHandle;
+
+/* hipMalloc `bytes` on the handle's device and export it. */
+int vdyn_xchg_alloc(VdynHandle *h, uint64_t bytes, void **dev_ptr, VdynIpcHandle *out);
+int vdyn_xchg_free(VdynHandle *h, void *dev_ptr);
+/* Map a peer process's buffer (not your own: use the pointer vdyn_xchg_alloc returned). */
+int vdyn_xchg_open(VdynHandle *h, const VdynIpcHandle *peer, void **peer_ptr);
+int vdyn_xchg_close(VdynHandle *h, void *peer_ptr);
+/* Copy `bytes` from src (this device) to dst[i] + dst_offset for i < n_dst, on the handle's copy
+ * stream, after everything enqueued so far on `after_stream` (the compute stream; NULL = default).
+ * Returns without waiting.  At most 64 destinations.                                            */
+int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
+                   uint64_t bytes, void *after_stream);
+/* Block the host until this handle's pushes have landed (a no-op when none is in flight). */
+int vdyn_xchg_wait(VdynHandle *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,22 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_rollout_fleet_{_s}_dev"] = (_int, _rf + [_vp])
     SIGNATURES[f"vdyn_rollout_fleet_{_s}_host"] = (_int, _rf)
 
+
+class VdynIpcHandle(C.Structure):
+    """Mirror of ``struct VdynIpcHandle`` (include/vdyn.h): an exported device buffer, 64 opaque bytes."""
+    _fields_ = [("bytes", C.c_ubyte * 64)]
+
+
+_u64 = C.c_uint64
+SIGNATURES.update({
+    "vdyn_xchg_alloc": (_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(VdynIpcHandle)]),
+    "vdyn_xchg_free": (_int, [_vp, _vp]),
+    "vdyn_xchg_open": (_int, [_vp, C.POINTER(VdynIpcHandle), C.POINTER(_vp)]),
+    "vdyn_xchg_close": (_int, [_vp, _vp]),
+    "vdyn_xchg_push": (_int, [_vp, C.POINTER(_vp), _i32, _u64, _vp, _u64, _vp]),
+    "vdyn_xchg_wait": (_int, [_vp]),
+})
+
 _lib = None
 
 

@@ -26,6 +26,9 @@ struct VdynHandle {
     size_t d_aux_bytes = 0;
     void *d_cand = nullptr;         // MPC candidate table with the steering angles' (sin, cos) per entry
     size_t d_cand_bytes = 0;
+    hipStream_t copy_stream = nullptr;   // peer exchange (vdyn_xchg_*): copies run here, beside the compute stream
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool push_in_flight = false;
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -166,6 +169,9 @@ void vdyn_destroy(VdynHandle *h)
     if (h->d_fleet) (void)hipFree(h->d_fleet);
     if (h->d_aux) (void)hipFree(h->d_aux);
     if (h->d_cand) (void)hipFree(h->d_cand);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     delete h;
 }
 
@@ -186,6 +192,88 @@ int vdyn_stream_synchronize(VdynHandle *h, void *stream)
     if (!h) return VDYN_ERR_ARG;
     VDYN_HIP(h, hipSetDevice(h->device));
     VDYN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    return VDYN_OK;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(VdynIpcHandle), "VdynIpcHandle too small for hipIpcMemHandle_t");
+
+int vdyn_xchg_alloc(VdynHandle *h, uint64_t bytes, void **dev_ptr, VdynIpcHandle *out)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (!dev_ptr || !out || bytes == 0) return h->fail(VDYN_ERR_ARG, "xchg_alloc: null argument or zero size");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return h->fail(VDYN_ERR_OOM, "xchg_alloc: hipMalloc failed"); }
+    hipIpcMemHandle_t ipc;
+    hipError_t e = hipIpcGetMemHandle(&ipc, p);
+    if (e != hipSuccess) { (void)hipFree(p); return h->fail_hip("hipIpcGetMemHandle", e); }
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->bytes, &ipc, sizeof(ipc));
+    *dev_ptr = p;
+    return VDYN_OK;
+}
+
+int vdyn_xchg_free(VdynHandle *h, void *dev_ptr)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (!dev_ptr) return VDYN_OK;
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, hipFree(dev_ptr));
+    return VDYN_OK;
+}
+
+int vdyn_xchg_open(VdynHandle *h, const VdynIpcHandle *peer, void **peer_ptr)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (!peer || !peer_ptr) return h->fail(VDYN_ERR_ARG, "xchg_open: null argument");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    hipIpcMemHandle_t ipc;
+    std::memcpy(&ipc, peer->bytes, sizeof(ipc));
+    VDYN_HIP(h, hipIpcOpenMemHandle(peer_ptr, ipc, hipIpcMemLazyEnablePeerAccess));
+    return VDYN_OK;
+}
+
+int vdyn_xchg_close(VdynHandle *h, void *peer_ptr)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (!peer_ptr) return VDYN_OK;
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, hipIpcCloseMemHandle(peer_ptr));
+    return VDYN_OK;
+}
+
+int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
+                   uint64_t bytes, void *after_stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (n_dst < 0 || n_dst > 64) return h->fail(VDYN_ERR_ARG, "xchg_push: 0..64 destinations");
+    if (n_dst == 0 || bytes == 0) return VDYN_OK;
+    if (!dst || !src) return h->fail(VDYN_ERR_ARG, "xchg_push: null pointer");
+    for (int i = 0; i < n_dst; ++i)
+        if (!dst[i]) return h->fail(VDYN_ERR_ARG, "xchg_push: null destination");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        VDYN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+        VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    }
+    VDYN_HIP(h, hipEventRecord(h->ev_ready, (hipStream_t)after_stream));      // the block is complete ...
+    VDYN_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_ready, 0));          // ... before any copy reads it
+    for (int i = 0; i < n_dst; ++i)
+        VDYN_HIP(h, hipMemcpyAsync(static_cast<char *>(dst[i]) + dst_offset, src, bytes, hipMemcpyDeviceToDevice,
+                                   h->copy_stream));
+    VDYN_HIP(h, hipEventRecord(h->ev_done, h->copy_stream));
+    h->push_in_flight = true;
+    return VDYN_OK;
+}
+
+int vdyn_xchg_wait(VdynHandle *h)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (!h->push_in_flight) return VDYN_OK;
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, hipEventSynchronize(h->ev_done));
+    h->push_in_flight = false;
     return VDYN_OK;
 }
 

@@ -106,9 +106,114 @@ class AllGatherExchange:
         self.wait()
 
 
-def make_exchange(kind: str, sh: ShardedRollout, rows: int, like: torch.Tensor):
+def slot_layout(world: int, rows: int, n_pad: int, itemsize: int):
+    """Byte geometry of a rank's slot buffer ``[world][rows][n_pad]``: (block_bytes, total_bytes,
+    [byte offset of rank r's slot])."""
+    block = int(rows) * int(n_pad) * int(itemsize)
+    return block, block * int(world), [r * block for r in range(int(world))]
+
+
+class _DeviceBuffer:
+    """A raw device pointer as something ``torch.as_tensor`` understands."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class PeerExchange:
+    """The same exchange without a collective kernel: every rank owns a slot buffer
+    ``[world][rows][n_pad]`` (exported once over IPC), and per step pushes its block into slot
+    ``rank`` of every rank's buffer with plain device-to-device copies on the library's copy
+    stream (``vdyn_xchg_*``, include/vdyn.h) -- SDMA / xGMI traffic that leaves the CUs to the next
+    rollout.  One process per GPU of ONE node.
+
+    ``start`` orders the copies behind the caller's current stream and returns; ``wait`` blocks the
+    host until THIS rank's copies have landed; a block pushed by another rank is known to have
+    landed once that rank waited and both passed a barrier -- ``result`` and bench.py's fence do
+    exactly that.  UNMEASURED on more than one GPU (none was available to the build); the
+    2-process test on one GPU exercises handles, slots and ordering."""
+
+    kind = "peer_copies"
+
+    def __init__(self, sh: ShardedRollout, rows: int, like: torch.Tensor, handle):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.sh, self.rows, self.h = sh, int(rows), handle
+        self.itemsize = like.element_size()
+        self.block, total, self.offsets = slot_layout(sh.world, rows, sh.n_pad, self.itemsize)
+        own, ipc = C.c_void_p(), _lib.VdynIpcHandle()
+        handle.call("vdyn_xchg_alloc", total, C.byref(own), C.byref(ipc))
+        self._own = own.value
+        typestr = {4: "<f4", 8: "<f8"}[self.itemsize]
+        self.recv = torch.as_tensor(_DeviceBuffer(self._own, (sh.world * self.rows, sh.n_pad), typestr),
+                                    device=like.device)
+        self.recv.zero_()
+        self.send = like.new_zeros((self.rows, sh.n_pad)) if sh.n_local != sh.n_pad else None
+        # every rank learns every rank's handle; its own buffer is used through the local pointer
+        blobs = [None] * sh.world
+        if sh.world > 1:
+            dist.all_gather_object(blobs, bytes(ipc.bytes), group=sh.group)
+        self._peers = []
+        ptrs = (C.c_void_p * sh.world)()
+        for r in range(sh.world):
+            if r == sh.rank:
+                ptrs[r] = self._own
+                continue
+            peer, hd = C.c_void_p(), _lib.VdynIpcHandle()
+            C.memmove(hd.bytes, blobs[r], 64)
+            handle.call("vdyn_xchg_open", C.byref(hd), C.byref(peer))
+            self._peers.append(peer.value)
+            ptrs[r] = peer.value
+        self._dst = ptrs
+        self._pending = None
+
+    def start(self, term_local: torch.Tensor):
+        assert self._pending is None, "wait() for the previous exchange first"
+        assert tuple(term_local.shape) == (self.rows, self.sh.n_local)
+        src = term_local.contiguous()
+        if self.send is not None:
+            self.send[:, :self.sh.n_local].copy_(term_local)
+            src = self.send
+        stream = self._C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+        self.h.call("vdyn_xchg_push", self._dst, self.sh.world, self.offsets[self.sh.rank],
+                    self._C.c_void_p(src.data_ptr()), self.block, stream)
+        self._pending = src                     # stays referenced until the copies have read it
+
+    def wait(self):
+        if self._pending is not None:
+            self.h.call("vdyn_xchg_wait")
+            self._pending = None
+
+    def result(self) -> torch.Tensor:
+        self.wait()
+        if dist.is_initialized() and self.sh.world > 1:
+            dist.barrier(group=self.sh.group)   # every rank has waited for its own pushes
+        torch.cuda.synchronize(self.recv.device)
+        return self.sh.assemble(self.recv, self.rows)
+
+    def close(self):
+        if self._own is None:
+            return
+        self.wait()
+        if dist.is_initialized() and self.sh.world > 1:
+            dist.barrier(group=self.sh.group)   # nobody is still writing into a buffer about to go
+        for p in self._peers:
+            self.h.call("vdyn_xchg_close", self._C.c_void_p(p))
+        self._peers = []
+        self.recv = None
+        self.h.call("vdyn_xchg_free", self._C.c_void_p(self._own))
+        self._own = None
+
+
+def make_exchange(kind: str, sh: ShardedRollout, rows: int, like: torch.Tensor, handle=None):
     if kind == "rccl":
         return AllGatherExchange(sh, rows, like)
+    if kind == "p2p":
+        if handle is None:
+            raise ValueError("the peer-copy exchange needs the rank's library handle")
+        return PeerExchange(sh, rows, like, handle)
     raise ValueError(f"unknown exchange {kind!r}")
 
 

@@ -164,6 +164,11 @@ class VehicleModel:
         self._handles = {}
         _lib.load()  # fail now, loudly, if the HIP library is not built
 
+    def handle(self, device=None):
+        """The library handle of `device` (default: this model's device), e.g. for
+        ``distributed.PeerExchange``."""
+        return self._handle(self.device if device is None else int(device))
+
     # ------------------------------------------------------------------ plumbing
     def _handle(self, device, p=None):
         cp = params_to_c(p if p is not None else self.params)

@@ -78,3 +78,26 @@ def test_shard_bounds_cover_everything(workloads):
             for (lo0, hi0), (lo1, hi1) in zip(b, b[1:]):
                 assert hi0 == lo1 and lo0 <= hi0
             assert all(lo % workloads.NUM_PATHS == 0 or lo == n for lo, _ in b)  # empty tail shards sit at n
+
+
+def test_peer_exchange_slot_arithmetic(pkg):
+    """Byte geometry of distributed.PeerExchange's slot buffers (the copies themselves need GPUs)."""
+    import importlib
+    D = importlib.import_module("python-motionplanning_amd.distributed")
+    block, total, offs = D.slot_layout(8, 12, 65534, 4)
+    assert block == 12 * 65534 * 4 and total == 8 * block and offs == [r * block for r in range(8)]
+    assert D.slot_layout(1, 12, 7, 8) == (672, 672, [0])
+    # slots tile the buffer exactly, in rank order, and match what assemble() reads back
+    import torch
+    sh = D.ShardedRollout(65)                       # one process: world 1
+    sh.world, sh.bounds = 3, [(0, 28), (28, 56), (56, 65)]
+    sh.n_pad = 28
+    flat = torch.zeros(3 * 12 * 28)
+    _, _, offs = D.slot_layout(3, 12, 28, 1)
+    for r, (lo, hi) in enumerate(sh.bounds):        # what rank r pushes: its padded block at its slot offset
+        blk = torch.zeros(12, 28)
+        blk[:, :hi - lo] = torch.arange(lo, hi, dtype=torch.float32)[None, :] + 1000.0 * torch.arange(12)[:, None]
+        flat[offs[r]:offs[r] + 12 * 28] = blk.reshape(-1)
+    full = sh.assemble(flat.view(3 * 12, 28), 12)
+    want = torch.arange(65, dtype=torch.float32)[None, :] + 1000.0 * torch.arange(12)[:, None]
+    assert torch.equal(full, want)

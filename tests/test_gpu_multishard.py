@@ -62,3 +62,29 @@ def test_mpc_config5_full_size_vs_oracle(gpu_vm, oracle, workloads):
     assert np.abs(cost64 - ocost).max() <= 1e-9
     assert np.array_equal(bi64, obi)
     assert np.abs(bc64 - obc).max() <= 1e-9
+
+
+@pytest.mark.parametrize("n", [70 * 64, 65 * 64 + 3])          # equal shards; ragged (padded blocks, partial last ego)
+def test_peer_copy_exchange_two_processes_one_gpu(tmp_path, gpu_vm, workloads, n):
+    """distributed.PeerExchange (the exchange that leaves the CUs alone: IPC-exported slot buffers,
+    device-to-device copies on a copy stream) with two processes on the one GPU of the box: every rank
+    must end up with all terminal blocks, bit for bit the single launch."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H = 40
+    entry = os.path.join(repo, "tests", "_peer_exchange_entry.py")
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.spawn_ranks(2, %r, script=%r))" % (repo, [str(tmp_path), str(n), str(H)], entry))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    s0, tab, pid = workloads.config3(n, H, np.float32)
+    dev = torch.device("cuda:0")
+    single = gpu_vm(1e-3).rollout(torch.from_numpy(s0).to(dev), torch.from_numpy(tab).to(dev),
+                                  path_id=torch.from_numpy(pid).to(dev)).cpu().numpy()
+    for r in range(2):
+        got = np.load(tmp_path / f"p2p_rank{r}.npy")
+        assert got.shape == single.shape and np.array_equal(got, single)
