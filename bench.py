@@ -478,6 +478,12 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = timed_launches(lambda: vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA), 5, torch)
     ex["config5_mpc_1024x512x50_f32"] = {"steps_per_s": E * C * H / t, "kernel_ms": t * 1e3,
                                          "rollouts_per_s": E * C / t}
+    # lattice-driven rollouts ("realistic alternative"): every rollout steers along
+    # its own cubic spiral, evaluated in the kernel -- 12 B per rollout instead of a control horizon
+    s0s, sps = (torch.from_numpy(a).to(dev) for a in W.config3_spiral(N_PER_GPU, HORIZON, np.float32))
+    vm.rollout_spiral(s0s, sps, HORIZON)
+    t = timed_launches(lambda: vm.rollout_spiral(s0s, sps, HORIZON), 5, torch)
+    ex["spiral_lattice_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3, "bytes_per_rollout_controls": 12}
     # closed loop: Stanley + PID every 10 sub-steps against 7 LDS-staged
     # waypoint tables of 1024 points, RK4 every sub-step
     cl = [torch.from_numpy(a).to(dev) for a in W.closed_loop_config(N_PER_GPU, dtype=np.float32)]
@@ -529,6 +535,25 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     run_lat()
     t = timed_launches(run_lat, 3, torch)
     ex["plan_lattice_9363x7_f64"] = {"ms": t * 1e3, "spirals_per_s": Ego * 7 / t, "planning_cycles_per_s": Ego / t}
+    # plan -> dynamic rollout of the planned spirals -> collision check / best path, device to device:
+    # 9363 egos x 7 lattice paths (65541 rollouts) x 200 steps of 1 ms, every 10th state kept for the selection
+    s_p = np.zeros((12, Ego * 7), dtype=np.float32)
+    s_p[0], s_p[3:7] = 25.0, 25.0 / W.DEFAULT_RW
+    s_p[8], s_p[9], s_p[7] = (np.repeat(ego[i], 7) for i in (0, 1, 2))
+    s_p = torch.from_numpy(s_p).to(dev)
+    lat32 = [a.float() for a in lat_in]
+    obst32 = torch.from_numpy(np.stack([gpx[::97] * 1.02, gpy[::97] * 1.02], axis=1).astype(np.float32)).to(dev)
+
+    def pipeline():
+        lat = vm.plan_lattice(lat32[0], lat32[1], lat32[2], 25.0)
+        _, traj = vm.rollout_spiral(s_p, lat["params"], HORIZON, torque=100.0, traj_stride=10)
+        gi = lat["goal_index"].long()
+        return vm.select_best_rollout(traj, 7, obst32, torch.stack([lat32[0][gi], lat32[1][gi]]))
+
+    pipeline()
+    t = timed_launches(pipeline, 3, torch)
+    ex["lattice_pipeline_9363x7x200_f32"] = {"ms": t * 1e3, "egos_per_s": Ego / t, "rollout_steps_per_s": Ego * 7 * HORIZON / t,
+                                             "stages": "plan_lattice -> rollout_spiral (traj every 10) -> select_best_rollout"}
     # one whole frame of the reference's Car.drive (drive.py:112-154) for a fleet, device to device:
     # plan the lattice, check collisions / pick the best path, re-interpolate it into each ego's
     # Stanley table (1 cm spacing), then 100 sub-steps of controllers + RK4 against that table

@@ -161,6 +161,30 @@ int vdyn_rollout_f32_host(VdynHandle *h, int64_t n, int32_t H, const float *stat
                           double dt, const double *mu4, float *terminal, float *traj,
                           int32_t traj_stride);
 
+/* ---- lattice-driven rollout: every rollout steers along its own cubic spiral -------------------
+ * The conformal-lattice planner gives every (ego, lateral offset) a cubic spiral kappa(s) =
+ * a + b s + c s^2 + d s^3 from PathOptimizer.optimize_spiral (path_optimizer.py:31-88); spiral [n][3]
+ * = (p1, p2, sf) per rollout is exactly the `params` output of vdyn_plan_lattice_* ([E][P][3], rollout
+ * r = ego r / P, path r % P) and is mapped to (a, b, c, d) by path_optimizer.py:149-154.  Step t
+ * (0-based) applies  delta_t = clip(atan(wheelbase * kappa(min(U0 t dt, sf))), +-max_steer)  on both
+ * front wheels (drive.py:143 pattern: [d, d, 0, 0], torques [torque x4], mu_max = mu4 or ones),
+ * U0 = the rollout's initial speed state0[0]: the kinematic-bicycle steering angle of the planned
+ * curvature at the arc length a vehicle holding its speed has covered.
+ * The clip is stanley_controller.py:128's; max_steer >= pi/2 disables it.  No control array at all.
+ * -> terminal [12][n], traj (nullable) [H / traj_stride][12][n] as vdyn_rollout_*.                  */
+int vdyn_rollout_spiral_f64_dev(VdynHandle *h, int64_t n, int32_t H, const double *state0, const double *spiral,
+                                double wheelbase, double max_steer, double torque, double dt, const double *mu4,
+                                double *terminal, double *traj, int32_t traj_stride, void *stream);
+int vdyn_rollout_spiral_f32_dev(VdynHandle *h, int64_t n, int32_t H, const float *state0, const float *spiral,
+                                double wheelbase, double max_steer, double torque, double dt, const double *mu4,
+                                float *terminal, float *traj, int32_t traj_stride, void *stream);
+int vdyn_rollout_spiral_f64_host(VdynHandle *h, int64_t n, int32_t H, const double *state0, const double *spiral,
+                                 double wheelbase, double max_steer, double torque, double dt, const double *mu4,
+                                 double *terminal, double *traj, int32_t traj_stride);
+int vdyn_rollout_spiral_f32_host(VdynHandle *h, int64_t n, int32_t H, const float *state0, const float *spiral,
+                                 double wheelbase, double max_steer, double torque, double dt, const double *mu4,
+                                 float *terminal, float *traj, int32_t traj_stride);
+
 /* ---- rollout of a heterogeneous fleet ------------------------------------------------------
  * As vdyn_rollout_*, but every rollout has its own vehicle class: classes [V] (HOST array of
  * VdynParams, 1 <= V <= 256: different masses, geometry, Pacejka B / C ...), vehicle_id [n]

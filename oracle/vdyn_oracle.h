@@ -45,6 +45,10 @@ typedef struct OracleCtrlParams {
                            const REAL *state0, const REAL *ctrl, int k, int layout,            \
                            const int *path_id, int P, const double *mu4, REAL *terminal,       \
                            REAL *traj, int traj_stride, int nthreads);                         \
+    int oracle_rollout_spiral_##S(const OracleParams *p, long n, int H, double dt, const REAL *state0,  \
+                                  const REAL *spiral, double wheelbase, double max_steer,               \
+                                  double torque_all, const double *mu4, REAL *terminal, REAL *traj,     \
+                                  int traj_stride, REAL *delta_out, int nthreads);                      \
     void oracle_stanley_control_##S(const OracleCtrlParams *g, const REAL *wp, int W, int stride,       \
                                     REAL x, REAL y, REAL yaw, REAL v, REAL *out);                       \
     void oracle_long_control_##S(const OracleCtrlParams *g, REAL desired, REAL current, REAL prev,      \

@@ -76,7 +76,7 @@ def build(case, pkg, torch, dev):
             dynamic_lds_bytes=lds)
     if case == "spiral_lattice":
         n, H = 65536, 200
-        s0, sp, U = W.config3_spiral(n, H, np.float32)
+        s0, sp = W.config3_spiral(n, H, np.float32)
         s0d, spd = torch.from_numpy(s0).to(dev), torch.from_numpy(sp).to(dev)
         return (lambda: vm.rollout_spiral(s0d, spd, H)), dict(
             kernel="rollout_spiral_kernel<float", steps_per_lane=H, vehicle_steps=n * H,

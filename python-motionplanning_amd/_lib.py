@@ -69,6 +69,11 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_mpc_argmin_{_s}_host"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _dbl, _dbl,
                                                        _vp, _vp, _vp])
 
+for _s in ("f32", "f64"):
+    _rs = [_vp, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _vp, _i32]
+    SIGNATURES[f"vdyn_rollout_spiral_{_s}_dev"] = (_int, _rs + [_vp])
+    SIGNATURES[f"vdyn_rollout_spiral_{_s}_host"] = (_int, _rs)
+
 _gp = C.POINTER(VdynCtrlGains)
 for _s in ("f32", "f64"):
     _cu = [_vp, _gp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp]

@@ -325,6 +325,26 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     return VDYN_OK;
 }
 
+template <typename T>
+int rollout_spiral_dev(VdynHandle *h, int64_t n, int32_t H, const T *state0, const T *spiral, double wheelbase,
+                       double max_steer, double torque, double dt, const double *mu4, T *terminal, T *traj,
+                       int32_t traj_stride, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (n < 0 || H < 0) return h->fail(VDYN_ERR_ARG, "rollout_spiral: n < 0 or H < 0");
+    if (!std::isfinite(dt) || !std::isfinite(wheelbase) || !std::isfinite(torque) || std::isnan(max_steer) || max_steer < 0)
+        return h->fail(VDYN_ERR_ARG, "rollout_spiral: dt / wheelbase / torque must be finite, max_steer >= 0");
+    if (n == 0) return VDYN_OK;
+    if (!state0 || !spiral || !terminal) return h->fail(VDYN_ERR_ARG, "rollout_spiral: null buffer");
+    if (traj && traj_stride <= 0) return h->fail(VDYN_ERR_ARG, "rollout_spiral: traj needs traj_stride > 0");
+    const double half_pi = 1.5707963267948966;
+    const double tan_max = max_steer >= half_pi ? INFINITY : std::tan(max_steer);
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_rollout_spiral<T>(h->p, n, H, state0, spiral, wheelbase, tan_max, torque, dt, mu4,
+                                               terminal, traj, traj_stride, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
 // Fleet rollout: build the per-class table on the host, put it on the device (a small pageable
 // copy, enqueued on the caller's stream in front of the kernel), launch.
 template <typename T>
@@ -554,6 +574,27 @@ int rollout_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
     a.state_dot = s.dev<T>(o2, true);
     a.outputs = s.dev<T>(o3, true);
     rc = rollout_dev<T>(h, a, h->stream, who);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+int rollout_spiral_host(VdynHandle *h, int64_t n, int32_t H, const T *state0, const T *spiral, double wheelbase,
+                        double max_steer, double torque, double dt, const double *mu4, T *terminal, T *traj,
+                        int32_t traj_stride)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (n <= 0 || H < 0 || !state0 || !spiral || !terminal || (traj && traj_stride <= 0))
+        return rollout_spiral_dev<T>(h, n, H, state0, spiral, wheelbase, max_steer, torque, dt, mu4, terminal, traj,
+                                     traj_stride, h->stream);      // n == 0, or reports the precise argument error
+    const size_t e = sizeof(T) * (size_t)n;
+    Stage s(h);
+    const size_t i0 = s.in(state0, 12 * e), i1 = s.in(spiral, 3 * e);
+    const size_t o0 = s.out(terminal, 12 * e), o1 = s.out(traj, traj ? (size_t)(H / traj_stride) * 12 * e : 0);
+    int rc = s.upload();
+    if (rc) return rc;
+    rc = rollout_spiral_dev<T>(h, n, H, s.dev<T>(i0, false), s.dev<T>(i1, false), wheelbase, max_steer, torque, dt, mu4,
+                               s.dev<T>(o0, true), s.dev<T>(o1, true), traj_stride, h->stream);
     if (rc) return rc;
     return s.download();
 }
@@ -1023,8 +1064,28 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
         return interp_host<T>(h, E, P, L, paths, best_idx, res, Wmax, wp_out, wcount);                   \
     }
 
+#define VDYN_DEFINE_SPIRAL_ABI(S, T)                                                                     \
+    extern "C" int vdyn_rollout_spiral_##S##_dev(VdynHandle *h, int64_t n, int32_t H, const T *state0,   \
+                                                 const T *spiral, double wheelbase, double max_steer,    \
+                                                 double torque, double dt, const double *mu4,            \
+                                                 T *terminal, T *traj, int32_t traj_stride, void *stream) \
+    {                                                                                                    \
+        return rollout_spiral_dev<T>(h, n, H, state0, spiral, wheelbase, max_steer, torque, dt, mu4, terminal, \
+                                     traj, traj_stride, stream);                                         \
+    }                                                                                                    \
+    extern "C" int vdyn_rollout_spiral_##S##_host(VdynHandle *h, int64_t n, int32_t H, const T *state0,  \
+                                                  const T *spiral, double wheelbase, double max_steer,   \
+                                                  double torque, double dt, const double *mu4,           \
+                                                  T *terminal, T *traj, int32_t traj_stride)             \
+    {                                                                                                    \
+        return rollout_spiral_host<T>(h, n, H, state0, spiral, wheelbase, max_steer, torque, dt, mu4, terminal, \
+                                      traj, traj_stride);                                                \
+    }
+
 VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
+VDYN_DEFINE_SPIRAL_ABI(f32, float)
+VDYN_DEFINE_SPIRAL_ABI(f64, double)
 VDYN_DEFINE_LATTICE_ABI(f32, float)
 VDYN_DEFINE_LATTICE_ABI(f64, double)
 VDYN_DEFINE_FLEET_ABI(f32, float)

@@ -148,18 +148,21 @@ struct StepInv {
 // K2 = true: the drive.py:142-143 pattern -- delta[1] == delta[0], rear angles exactly
 // 0, so one sincos serves the front axle and the rear rotations are the identity
 // (x*1 + y*0 == x in IEEE) and are skipped.
-// PRE (FAST only): sin / cos of the front steering angle arrive precomputed (sd0, cd0), evaluated by
-// the same Math<T, false>::sincos when an LDS-shared control table was staged.
-template <typename T, bool K2, bool SAFE, bool PRE = false>
+// PRE (FAST only): sin / cos of the front steering angle arrive precomputed (sd0, cd0).
+//   1: evaluated by the same Math<T, false>::sincos when an LDS-shared control table was staged;
+//      delta[0] is the angle itself and is range-checked as usual;
+//   2: exact (cos = 1 / sqrt(1 + tan^2), sin = tan cos, any angle): delta[0] holds TAN(delta), the form
+//      a curvature-driven rollout produces (tan delta = L kappa); the SAFE redo takes the arctangent.
+template <typename T, bool K2, bool SAFE, int PRE = 0>
 __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T delta[4], const T tq[4],
                                               const T mu[4], T ax_prev, T ay_prev, StepInv<T> &c, bool &ok,
                                               T sd0 = T(0), T cd0 = T(1))
 {
     using M = Math<T, SAFE>;
-    if (PRE && !SAFE) {
+    if (PRE != 0 && !SAFE) {
         c.sd[0] = sd0;
         c.cd[0] = cd0;
-        ok = ok && (abs_t(delta[0]) <= steer_limit_t(T(0)));
+        if (PRE == 1) ok = ok && (abs_t(delta[0]) <= steer_limit_t(T(0)));
     } else {
         M::sincos(delta[0], &c.sd[0], &c.cd[0], ok);
     }
@@ -293,7 +296,7 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
 // sn[10], (axn, ayn), the latter the 1-2-2-1 averages of axc, ayc (:442-443).
 // DIAG: also state_dot (:440) and the averaged outputs (:441).
 // Returns false for a lane that left the validated range of the FAST path.
-template <typename T, bool K2, bool DIAG, bool SAFE, bool CS, bool PRE = false>
+template <typename T, bool K2, bool DIAG, bool SAFE, bool CS, int PRE = 0>
 __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T ax, T ay, const T delta[4],
                                          const T tq[4], const T mu[4], T h, T sn[10], T &axn, T &ayn,
                                          T *state_dot, Outputs18<T> *outputs, T sd0 = T(0), T cd0 = T(1))
@@ -360,7 +363,10 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 // One step for one lane: the FAST path, then SAFE for the lanes that need it.
 // The outer test is wave-uniform (one scalar branch, normally not taken); the
 // inner one restricts the redo to the lanes that asked for it.
-template <typename T, bool K2, bool DIAG, bool CS, bool PRE = false>
+__device__ __forceinline__ float atan_lib(float x) { return ::atanf(x); }
+__device__ __forceinline__ double atan_lib(double x) { return ::atan(x); }
+
+template <typename T, bool K2, bool DIAG, bool CS, int PRE = 0>
 __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                             const T tq[4], const T mu[4], T h, T *state_dot,
                                             Outputs18<T> *outputs, T sd0 = T(0), T cd0 = T(1))
@@ -370,7 +376,15 @@ __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &a
                                                           sd0, cd0);
     if (Math<T, false>::kHasRangeLimit) {
         if (__builtin_expect(__any(!ok) != 0, 0)) {
-            if (!ok) rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+            if (!ok) {
+                if (PRE == 2) {     // delta[0] is the tangent of the (front) steering angle
+                    const T a = atan_lib(delta[0]);
+                    const T dl[4] = {a, a, T(0), T(0)};
+                    rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, dl, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+                } else {
+                    rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+                }
+            }
         }
     }
 #pragma unroll

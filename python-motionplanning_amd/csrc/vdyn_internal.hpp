@@ -36,6 +36,12 @@ struct RolloutArgs {
 template <typename T>
 hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st);
 
+// lattice-driven rollout: spiral [n][3] = (p1, p2, sf) per rollout (the `params` output of plan_lattice)
+template <typename T>
+hipError_t launch_rollout_spiral(const VdynParams &p, int64_t n, int H, const T *state0, const T *spiral,
+                                 double wheelbase, double tan_max, double torque, double dt, const double *mu4,
+                                 T *terminal, T *traj, int traj_stride, hipStream_t st);
+
 template <typename T>
 hipError_t launch_rollout_fleet(const RolloutArgs<T> &a, bool all_small, hipStream_t st);
 template <typename T>

@@ -130,7 +130,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     T sd[10];
     Outputs18<T> o18;
     StepEngine<T> eng;
-    constexpr bool PRE = rollout_table_pre<K, LAYOUT, DIAG>();
+    constexpr int PRE = rollout_table_pre<K, LAYOUT, DIAG>() ? 1 : 0;
     if (!DIAG) eng.init(P);
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
@@ -196,6 +196,61 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 for (int i = 0; i < 18; ++i) outputs_out[(int64_t)i * n + r] = o18.v[i];
             }
         }
+    }
+}
+
+// Lattice-driven rollout: every rollout follows ITS OWN cubic spiral, the path the conformal-lattice planner
+// optimised for it (path_optimizer.py:31-88).  spiral [n][3] = (p1, p2, sf) per rollout -- exactly the `params`
+// output of vdyn_plan_lattice_* -- is mapped to the curvature polynomial kappa(s) = a + b s + c s^2 + d s^3
+// with the reference's own formulas (path_optimizer.py:149-154, p0 = p3 = 0), and step t steers with
+//   tan(delta_t) = L kappa(min(U0 t dt, sf)),  clipped to +- tan(max_steer)   (stanley_controller.py:128)
+// where U0 is the rollout's initial speed (the arc length a vehicle holding its speed has covered) and L
+// the wheelbase: the kinematic-bicycle steering angle of that curvature.
+// No control bytes come from memory at all: 12 B per ROLLOUT instead of 8 B per step, and
+// (sin delta, cos delta) are exact from the tangent -- cos = rsq(1 + tan^2) -- with no arctangent.
+template <typename T, bool CS>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
+rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0, const T *__restrict__ spiral,
+                      T wheelbase, T tan_max, T torque, T h, T *__restrict__ terminal, T *__restrict__ traj,
+                      int traj_stride)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gid < n;
+    const int64_t r = active ? gid : n - 1;
+    typename StepEngine<T>::State X;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) X.set(i, state0[(int64_t)i * n + r]);
+    StepEngine<T> eng;
+    eng.init(P);
+
+    const T p1 = spiral[3 * r], p2 = spiral[3 * r + 1], sf = spiral[3 * r + 2];
+    // path_optimizer.py:149-154 with p0 = p3 = 0 (a = 0), pre-multiplied by the wheelbase: q = tan(delta)
+    const T isf = T(1) / sf;
+    const T qb = wheelbase * (-(T(-9) * p1 + T(4.5) * p2) * isf);
+    const T qc = wheelbase * ((T(-22.5) * p1 + T(18) * p2) * isf * isf);
+    const T qd = wheelbase * (-(T(-13.5) * p1 + T(13.5) * p2) * isf * isf * isf);
+    const T ds = X.get(0) * h;                                    // arc length per step at the initial speed
+    const T tq[4] = {torque, torque, torque, torque};
+
+    for (int t = 0; t < H; ++t) {
+        T s = ds * (T)t;
+        s = s < sf ? s : sf;
+        T q = s * fma_t(s, fma_t(s, qd, qc), qb);
+        q = q < -tan_max ? -tan_max : q;                           // np.clip semantics: NaN passes through
+        q = q > tan_max ? tan_max : q;
+        const T cd = Math<T, false>::rsqrt(fma_t(q, q, T(1)));
+        const T sd = q * cd;
+        const T delta[4] = {q, q, T(0), T(0)};                     // PRE = 2: the tangent stands in for the angle
+        eng.template advance_state<true, CS, 2>(P, X, delta, tq, P.mu, h, sd, cd);
+        if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+            T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), row + (int64_t)i * n);
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) terminal[(int64_t)i * n + r] = X.get(i);
     }
 }
 
@@ -453,7 +508,7 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         for (int t = 0; t < H; ++t) {
             Ctrl<T, 2> cn;
             cn.set_pre(P, cand4 + ((int64_t)min(t + 1, H - 1) * C + c) * 4);
-            eng.template advance_state<true, CS, true>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
             cc = cn;
         }
@@ -1134,6 +1189,23 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
 }
 
 template <typename T>
+hipError_t launch_rollout_spiral(const VdynParams &p, int64_t n, int H, const T *state0, const T *spiral,
+                                 double wheelbase, double tan_max, double torque, double dt, const double *mu4,
+                                 T *terminal, T *traj, int traj_stride, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const DevParams<T> P = make_dev_params<T>(p, mu4);
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (shape_factors_small(p))
+        hipLaunchKernelGGL((rollout_spiral_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral,
+                           (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1);
+    else
+        hipLaunchKernelGGL((rollout_spiral_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral,
+                           (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1);
+    return hipGetLastError();
+}
+
+template <typename T>
 hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, const T *ctrl12,
                                const T *acc_prev, T *state_dot, T *aux, T *outputs, T *acc,
                                hipStream_t st)
@@ -1310,6 +1382,8 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
 
 #define VDYN_INSTANTIATE(T)                                                                          \
     template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
+    template hipError_t launch_rollout_spiral<T>(const VdynParams &, int64_t, int, const T *, const T *, double, \
+                                                 double, double, double, const double *, T *, T *, int, hipStream_t); \
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
                                                const T *, T *, T *, T *, T *, hipStream_t);          \
     template hipError_t launch_mpc_argmin<T>(const VdynParams &, int, int, int, const T *, const T *, \

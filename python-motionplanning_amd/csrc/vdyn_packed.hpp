@@ -421,7 +421,8 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
 // DIAG: also state_dot (:440) and the 1-2-2-1 averaged outputs (:441).
 // PRE: (sin, cos) of the front steering angle arrive precomputed (LDS-shared control tables hold
 // them per entry; computed by the same sincos_kernel2, so the result is bit for bit the same).
-template <bool K2, bool CS, bool DIAG = false, bool PRE = false>
+// PRE = 2: delta[0] holds tan(delta) and (sin, cos) are exact for any angle (no range check).
+template <bool K2, bool CS, bool DIAG = false, int PRE = 0>
 __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkParams &Q, const PkConsts &K,
                                           const State5 &s, f2 axy, const float delta[4], const float tq[4],
                                           const float mu[4], float h, State5 &acc, f2 &axy_n,
@@ -432,9 +433,9 @@ __device__ __forceinline__ bool rk4_step2(const DevParams<float> &P, const PkPar
     StepInv2 c;
     {
         f2 d0;
-        if (PRE) {
+        if (PRE != 0) {
             d0 = steer_sc;
-            ok = ok && (::fabsf(delta[0]) <= fm::kSincosKernelLimit);
+            if (PRE == 1) ok = ok && (::fabsf(delta[0]) <= fm::kSincosKernelLimit);
         } else {
             d0 = sincos_steer2(K, delta[0], ok);
         }
@@ -541,7 +542,7 @@ struct StepEngine {
         __device__ __forceinline__ T get(int i) const { return i < 10 ? s[i] : (i == 10 ? ax : ay); }
         __device__ __forceinline__ void set(int i, T v) { if (i < 10) s[i] = v; else if (i == 10) ax = v; else ay = v; }
     };
-    template <bool K2, bool CS, bool PRE = false>
+    template <bool K2, bool CS, int PRE = 0>
     __device__ __forceinline__ void advance_state(const DevParams<T> &P, State &X, const T delta[4], const T tq[4],
                                                   const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
     {
@@ -554,7 +555,7 @@ struct StepEngine {
         bool ok = true;
         Math<T, false>::sincos(d, &sd, &cd, ok);
     }
-    template <bool K2, bool CS, bool PRE = false>
+    template <bool K2, bool CS, int PRE = 0>
     __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                             const T tq[4], const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
     {
@@ -610,7 +611,7 @@ struct StepEngine<float> {
             }
         }
     };
-    template <bool K2, bool CS, bool PRE = false>
+    template <bool K2, bool CS, int PRE = 0>
     __device__ __forceinline__ void advance_state(const DevParams<float> &P, State &X, const float delta[4],
                                                   const float tq[4], const float mu[4], float h, float sd0 = 0.0f,
                                                   float cd0 = 1.0f) const
@@ -630,7 +631,9 @@ struct StepEngine<float> {
                 float s[10], sn[10], axn, ayn;
 #pragma unroll
                 for (int i = 0; i < 10; ++i) s[i] = X.get(i);
-                rk4_step<float, K2, false, true, CS>(P, s, X.axy.x, X.axy.y, delta, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
+                float dl[4] = {delta[0], delta[1], delta[2], delta[3]};
+                if (PRE == 2) dl[0] = dl[1] = ::atanf(delta[0]);        // delta[0] is tan(delta)
+                rk4_step<float, K2, false, true, CS>(P, s, X.axy.x, X.axy.y, dl, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
 #pragma unroll
                 for (int i = 0; i < 10; ++i) X.set(i, sn[i]);
                 X.axy = f2{axn, ayn};
@@ -649,7 +652,7 @@ struct StepEngine<float> {
         }
     }
     // the same step on the [10] + 2 scalar form (kernels that read single states between steps)
-    template <bool K2, bool CS, bool PRE = false>
+    template <bool K2, bool CS, int PRE = 0>
     __device__ __forceinline__ void advance(const DevParams<float> &P, float s[10], float &ax, float &ay,
                                             const float delta[4], const float tq[4], const float mu[4],
                                             float h, float sd0 = 0.0f, float cd0 = 1.0f) const

@@ -341,6 +341,37 @@ class VehicleModel:
         del keep
         return (term, traj) if traj_stride > 0 else term
 
+    def rollout_spiral(self, states0, spiral_params, H, torque=100.0, dt=None, max_steer=None, mu_max=None,
+                       traj_stride=0, p=None):
+        """Lattice-driven rollouts: ``spiral_params [N][3]`` = (p1, p2, sf) per rollout -- the ``params``
+        output of ``plan_lattice`` (``[E][P][3]`` is accepted and flattened: rollout r = ego r // P, path
+        r % P) -- and step t steers both front wheels with
+        ``clip(atan(wheelbase * kappa(min(U0 t dt, sf))), +-max_steer)``, kappa the cubic spiral of
+        path_optimizer.py:149-154, U0 = states0[0].  No control array is read.  ``max_steer`` defaults to
+        this model's (VehicleModel(wheelbase, max_steer, dt), drive.py:109)."""
+        be = _Backend(states0)
+        s0 = be.inp(states0)
+        if s0.ndim != 2 or s0.shape[0] != 12:
+            raise ValueError("states0 must be [12][N]")
+        n = s0.shape[1]
+        sp = be.inp(spiral_params)
+        if sp.ndim == 3:
+            sp = sp.reshape(-1, 3)
+        if tuple(sp.shape) != (n, 3):
+            raise ValueError("spiral_params must be [N][3] (or [E][P][3] with E * P == N)")
+        sp = sp.contiguous() if be.torch else np.ascontiguousarray(sp)
+        if H < 0 or traj_stride < 0:
+            raise ValueError("need H >= 0 and traj_stride >= 0")
+        keep, mu4 = self._mu4(mu_max)
+        term = be.out(12, n)
+        traj = be.out(int(H) // traj_stride, 12, n) if traj_stride > 0 else None
+        self._handle(be.device_index(self.device), p).call(
+            f"vdyn_rollout_spiral_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(sp), float(self.wheelbase),
+            float(self.max_steer if max_steer is None else max_steer), float(torque),
+            float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj), int(traj_stride), *be.stream_args())
+        del keep
+        return (term, traj) if traj_stride > 0 else term
+
     def rollout_fleet(self, states0, controls, classes, vehicle_id, dt=None, path_id=None, mu_max=None,
                       traj_stride=0):
         """``rollout`` for a heterogeneous fleet: ``classes`` is a sequence of VehicleParameters-like

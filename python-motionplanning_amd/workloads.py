@@ -94,6 +94,23 @@ def config3(n=65536, H=200, dtype=np.float32, seed=20240):
             lattice_controls(H, dtype=dtype), path_id)
 
 
+def config3_spiral(n=65536, H=200, dtype=np.float32, seed=20240, seed_sf=20245):
+    """Config 3 with lattice-driven steering ("realistic alternative"): the same
+    egos and rollout -> (ego r // 7, path r % 7) map as ``config3``; rollout r follows a cubic spiral
+    (p1, p2, sf) that changes lane by (k - 3) * 2 m (drive.py:21,24) over sf ~ U[25, 35] m per ego:
+    the antisymmetric spiral p1 = -p2 = q has kappa(s) = 13.5 q u (1 - u)(1 - 2u), u = s / sf, and a
+    lateral end offset of 0.225 q sf^2.  Returns state0 [12][n], spiral [n][3].  (H is unused: the
+    steering comes from the spiral, not from a table.)"""
+    state0, _, path_id = config3(n, H, dtype, seed)
+    n_ego = -(-n // NUM_PATHS)
+    sf_e = np.random.default_rng(seed_sf).uniform(25.0, 35.0, n_ego)
+    r = np.arange(n)
+    sf = sf_e[r // NUM_PATHS]
+    q = (path_id - NUM_PATHS // 2) * PATH_OFFSET / (0.225 * sf * sf)
+    spiral = np.stack([q, -q, sf], axis=1)
+    return state0, np.ascontiguousarray(spiral.astype(dtype))
+
+
 def expand_shared_controls(table, path_id):
     """[P][H][2] + path_id[N] -> per-rollout time-major [H][2][N]."""
     return np.ascontiguousarray(np.transpose(table[path_id], (1, 2, 0)))

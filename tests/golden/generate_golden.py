@@ -21,6 +21,8 @@ Sets:
   G6 the reference fed float32 arrays on the G3 inputs (fp32 floor, informational)
   G7 config-5 shaped MPC case (4 egos x 16 candidates x 50 steps)
   G8 config-3 shaped case (16 egos x 7 lattice paths x 200 steps)
+  G12 lattice-driven rollouts: spiral parameters from the reference's PathOptimizer for 4 egos x 7
+     lateral goals, the steering sequences they imply, terminal states from planar_model_RK4
   G9 closed-loop controller logs of the same 3-frame Car.drive run as G4 (world.path):
      the waypoint lists the planner handed to the Stanley controller, every
      stanley_control / long_control call (inputs -> outputs) and the steering filter
@@ -510,7 +512,76 @@ def g11():
     print("   opt_x[0]:", rec["opt"][0][1], "direct max nit", max(o[3] for o in rec["opt"][21:]))
 
 
+def g12():
+    """Lattice-driven rollouts: 4 egos x 7 lateral goal offsets.  The reference's own
+    PathOptimizer.optimize_spiral (path_optimizer.py:31-88, SciPy L-BFGS-B) gives every goal its
+    spiral parameters (p1, p2, sf); the steering sequence delta_t = clip(atan(2.906 kappa(min(U0 t dt,
+    sf))), +-30 deg) is computed here from them (kappa = a + b s + c s^2 + d s^3 with the mapping of
+    path_optimizer.py:148-154), and the reference's VehicleModel.planar_model_RK4 integrates 200
+    steps of 1 ms with delta = [d, d, 0, 0], torques 100 N m, mu_max 1 (drive.py:141-143)."""
+    import scipy.integrate
+    import scipy.optimize
+    if not hasattr(scipy.integrate, "cumtrapz"):
+        scipy.integrate.cumtrapz = scipy.integrate.cumulative_trapezoid
+    from libs.motionplanner.path_optimizer import PathOptimizer
+    H, dt, torque = 200, 1e-3, 100.0
+    U0s = [25.0, 15.0, 30.0, 20.0]
+    heads = [0.0, 0.10, -0.15, 0.05]
+    aheads = [30.0, 28.0, 32.0, 25.0]
+    xs = []
+    orig = scipy.optimize.minimize
+
+    def minimize(fun, x0, **kw):
+        r = orig(fun, x0, **kw)
+        xs.append(np.array(r.x, float))
+        return r
+
+    scipy.optimize.minimize = minimize
+    po = PathOptimizer()
+    goals, params = [], []
+    try:
+        for e in range(4):
+            for k in range(W.NUM_PATHS):
+                off = (k - W.NUM_PATHS // 2) * W.PATH_OFFSET            # drive.py:21,24; local_planner.py:260
+                xf = aheads[e] - off * np.sin(heads[e])
+                yf = off * np.cos(heads[e])
+                po.optimize_spiral(xf, yf, heads[e])
+                goals.append([xf, yf, heads[e]])
+                params.append(xs[-1])
+    finally:
+        scipy.optimize.minimize = orig
+    goals, params = np.array(goals), np.array(params)
+    rw = VehicleParameters().rw
+    n = len(params)
+    state0 = np.zeros((12, n))
+    delta = np.zeros((H, n))
+    abcd = np.zeros((n, 4))
+    term, snaps = [], []
+    for r in range(n):
+        U0 = U0s[r // W.NUM_PATHS]
+        state0[0, r] = U0
+        state0[3:7, r] = U0 / rw
+        p = [0.0, params[r, 0], params[r, 1], 0.0, params[r, 2]]
+        a = p[0]
+        b = -(11.0 * p[0] / 2.0 - 9.0 * p[1] + 9.0 * p[2] / 2.0 - p[3]) / p[4]
+        c = (9.0 * p[0] - 45.0 * p[1] / 2.0 + 18.0 * p[2] - 9.0 * p[3] / 2.0) / p[4] ** 2
+        d = -(9.0 * p[0] / 2.0 - 27.0 * p[1] / 2.0 + 27.0 * p[2] / 2.0 - 9.0 * p[3] / 2.0) / p[4] ** 3
+        abcd[r] = a, b, c, d
+        sa = np.minimum(U0 * dt * np.arange(H), p[4])
+        kap = a + b * sa + c * sa ** 2 + d * sa ** 3
+        delta[:, r] = np.clip(np.arctan(WHEELBASE * kap), -MAX_STEER, MAX_STEER)
+        seq = [expand2(delta[t, r], torque) for t in range(H)]
+        te, sn = ref_rollout(dt, state0[:, r], seq, every=20)
+        term.append(te); snaps.append(sn)
+    np.savez(os.path.join(HERE, "g12_spiral_rollouts.npz"), goals=goals, params=params, abcd=abcd, state0=state0,
+             delta=delta, terminal=np.array(term).T, every20=np.transpose(np.array(snaps), (1, 2, 0)),
+             dt=np.float64(dt), torque=np.float64(torque), wheelbase=np.float64(WHEELBASE),
+             max_steer=np.float64(MAX_STEER))
+    print("G12", params.shape, "max |delta| (deg)", np.rad2deg(np.abs(delta).max()),
+          "clipped steps", int((np.abs(delta) >= MAX_STEER).sum()), "sf range", params[:, 2].min(), params[:, 2].max())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

@@ -309,3 +309,27 @@ def test_g11_waypoint_interpolation(oracle):
         want = g9["waypoints"][f, :g9["waypoint_count"][f]]
         assert wp.shape == want.shape
         close(wp, want, 1e-12)
+
+
+def test_g12_spiral_rollouts_oracle_vs_reference(oracle):
+    """Lattice-driven rollouts: spiral parameters from the reference's PathOptimizer (L-BFGS-B), the
+    steering sequence they imply and the reference's planar_model_RK4 terminal states (G12)."""
+    from conftest import rel_err
+    g = load_golden("g12_spiral_rollouts.npz")
+    p = oracle.default_params()
+    H, dt, tq = g["delta"].shape[0], float(g["dt"]), float(g["torque"])
+    term, traj, dl = oracle.rollout_spiral(p, g["state0"], g["params"], H, dt, wheelbase=float(g["wheelbase"]),
+                                           max_steer=float(g["max_steer"]), torque=tq, traj_stride=20,
+                                           return_delta=True)
+    assert g["state0"].shape[1] == 28
+    assert np.abs(dl - g["delta"]).max() <= 1e-15, "steering sequence of the spiral"
+    assert rel_err(term, g["terminal"], 1e-6).max() <= 1e-10
+    assert rel_err(traj, g["every20"], 1e-6).max() <= 1e-10
+    # the same rollouts through the table-driven oracle path fed the golden delta sequence
+    ctrl = np.ascontiguousarray(np.stack([g["delta"], np.full_like(g["delta"], tq)], axis=1))   # [H][2][N]
+    assert rel_err(oracle.rollout(p, g["state0"], ctrl, dt), term, 1e-6).max() <= 1e-12
+    # clip (stanley_controller.py:128): a 2 degree limit bites on the outer lattice paths
+    lim = np.deg2rad(2.0)
+    _, d2 = oracle.rollout_spiral(p, g["state0"], g["params"], H, dt, max_steer=lim, torque=tq, return_delta=True)
+    assert np.abs(d2).max() <= lim and (np.abs(d2) == lim).any()
+    assert np.abs(d2 - np.clip(g["delta"], -lim, lim)).max() <= 1e-15
