@@ -27,32 +27,73 @@ struct CtrlGains {
 };
 
 template <typename T> struct Lib;
+// fp32: the library's atan2f / atanf / sincosf / fmodf cost 60-150 instructions each (full-range
+// reductions, special-case branches); the controllers call six of them per update.  The fp32 path is
+// held to 1e-3 on states (north_star), so it takes the bounded-cost forms of vdyn_fastmath.hpp (2 ulp)
+// where the argument allows and the library only beyond (|yaw| > 2^16).  fp64 stays on the library.
 template <> struct Lib<float> {
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
-    static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
-    static __device__ __forceinline__ float atan(float x) { return ::atanf(x); }
-    static __device__ __forceinline__ float fmod(float a, float b) { return ::fmodf(a, b); }
-    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
+    static __device__ __forceinline__ float atan(float x) { return fm::atan_rcp(x, fm::rcp(x)); }
+    static __device__ __forceinline__ float atan2(float y, float x)
+    {
+        const float ax = ::fabsf(x), ay = ::fabsf(y);
+        const float mx = ::fmaxf(ax, ay), mn = ::fminf(ax, ay);
+        float t = mn * fm::rcp(mx);
+        t = mx > 0.0f ? t : 0.0f;                                   // atan2(0, 0) = 0
+        t = (ax == ay && ax > 3.0e38f) ? 1.0f : t;                  // inf / inf
+        float p = fm::atan_rcp(t, 1.0f);                            // t in [0, 1]: the |x| > 1 branch is never taken
+        p = ay > ax ? 1.57079637050628662109375f - p : p;
+        p = x < 0.0f || (x == 0.0f && ::signbit(x)) ? 3.1415927410125732421875f - p : p;
+        p = (x != x || y != y) ? ::nanf("") : p;
+        return ::copysignf(p, y);
+    }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c)
+    {
+        if (::fabsf(x) <= fm::kSincosMidLimit) fm::sincos_mid(x, s, c);
+        else ::sincosf(x, s, c);
+    }
+    static __device__ __forceinline__ float div(float a, float b) { return a * fm::rcp(b); }
+    // (e + pi) mod 2 pi - pi, floor-mod, for |e| up to ~1e5: two-term Cody-Waite instead of fmodf
+    static __device__ __forceinline__ float wrap_pi(float e)
+    {
+        const float pi = 3.1415927410125732421875f;
+        if (!(::fabsf(e) <= 2.0e5f)) return wrap_pi_lib(e);
+        const float m = e + pi;
+        const float k = ::floorf(m * 0.159154943091895335769f);
+        float r = ::fmaf(-k, 6.283185482025146484375f, m);
+        r = ::fmaf(-k, -1.74845560007449713e-07f, r);
+        r = r < 0.0f ? r + 6.283185482025146484375f : r;            // rounding at the seam
+        r = r >= 6.283185482025146484375f ? r - 6.283185482025146484375f : r;
+        return r - pi;
+    }
+    static __device__ __forceinline__ float wrap_pi_lib(float e)
+    {
+        const float pi = 3.141592653589793f, two_pi = 6.283185307179586f;
+        float m = ::fmodf(e + pi, two_pi);
+        if (m < 0.0f) m += two_pi;
+        return m - pi;
+    }
     static constexpr float kTieBand = 1.0f - 16.0f * 1.1920929e-07f;
 };
 template <> struct Lib<double> {
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double atan(double x) { return ::atan(x); }
-    static __device__ __forceinline__ double fmod(double a, double b) { return ::fmod(a, b); }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
+    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    // (e + pi) % (2 pi) - pi with Python's floor-mod (stanley_controller.py:103,123)
+    static __device__ __forceinline__ double wrap_pi(double e)
+    {
+        const double pi = 3.141592653589793, two_pi = 2 * 3.141592653589793;
+        double m = ::fmod(e + pi, two_pi);
+        if (m < 0.0) m += two_pi;
+        return m - pi;
+    }
     static constexpr double kTieBand = 1.0 - 16.0 * 2.220446049250313e-16;
 };
 
-// (e + pi) % (2 pi) - pi with Python's floor-mod (stanley_controller.py:103,123)
 template <typename T>
-__device__ __forceinline__ T wrap_pi(T e)
-{
-    const T pi = T(3.141592653589793), two_pi = T(2 * 3.141592653589793);
-    T m = Lib<T>::fmod(e + pi, two_pi);
-    if (m < T(0)) m += two_pi;
-    return m - pi;
-}
+__device__ __forceinline__ T wrap_pi(T e) { return Lib<T>::wrap_pi(e); }
 
 // Waypoint access: a table of (x, y) pairs, either staged in LDS or read through L2, and
 // (optionally) the table of segment lengths seg[i] = |wp[i] - wp[i-1]| (seg[0] unused) that
@@ -162,9 +203,13 @@ __device__ __forceinline__ void nearest_in_range(const Waypoints<T> &wp, int lo,
 // at different places along the path do not pay for each other's blocks.  The bounds are read
 // eight at a time (one LDS / memory latency per eight circles); every inequality is slackened by
 // 1e-6 so that rounding can only widen the range (when in doubt, scan).
+// `hint` >= 0: any waypoint index (the nearest one of the previous controller update is the useful
+// choice: the vehicle has moved centimetres since).  |q - wp[hint]| is an upper bound of the minimum
+// distance too, and a far tighter one than pass 1 finds, so pass 1 is skipped.  The hint only prunes:
+// the result is the global first minimum either way.
 template <typename T, bool EXACT>
 __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, T x, T y, T &best_d2, int &best_i,
-                                                        bool &ambiguous)
+                                                        bool &ambiguous, int hint = -1)
 {
     best_d2 = T(INFINITY);
     best_i = 0;
@@ -172,7 +217,15 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, 
     const int nb = (wp.W + kWpBlock - 1) / kWpBlock;
     constexpr int kChunk = 8;
     T U = T(INFINITY);
-    for (int b0 = 0; b0 < nb; b0 += kChunk) {
+    const bool hinted = __all(hint >= 0) != 0;                   // wave-uniform: every lane brought a hint
+    if (hinted) {
+        T hx, hy;
+        wp.get(min(hint, wp.W - 1), hx, hy);
+        const T ex = hx - x, ey = hy - y;
+        U = (T)__builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey)) * T(1.000001) + T(1e-18);
+        U = U == U ? U : T(INFINITY);                            // NaN coordinates: no bound
+    }
+    for (int b0 = 0; b0 < (hinted ? 0 : nb); b0 += kChunk) {
         T ub[kChunk];
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
@@ -212,17 +265,19 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const Waypoints<T> &wp, 
 // stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
 template <typename T>
 __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Waypoints<T> &wp, T x, T y, T yaw,
-                                                T v, T &steer_out, int &idx_out, T &cte_out)
+                                                T v, T &steer_out, int &idx_out, T &cte_out, int *near_io = nullptr)
 {
     using L = Lib<T>;
     T best_d2;
     int best_i;
     bool amb;
     if (wp.bounds != nullptr) {
-        nearest_waypoint_pruned<T, false>(wp, x, y, best_d2, best_i, amb);
+        const int hint = near_io != nullptr ? *near_io : -1;
+        nearest_waypoint_pruned<T, false>(wp, x, y, best_d2, best_i, amb, hint);
         if (__builtin_expect(__any(amb) != 0, 0)) {      // wave-uniform, practically never taken
-            if (amb) nearest_waypoint_pruned<T, true>(wp, x, y, best_d2, best_i, amb);
+            if (amb) nearest_waypoint_pruned<T, true>(wp, x, y, best_d2, best_i, amb, hint);
         }
+        if (near_io != nullptr) *near_io = best_i;
     } else {
         nearest_waypoint<T, false>(wp, x, y, best_d2, best_i, amb);
         if (__builtin_expect(__any(amb) != 0, 0)) {
@@ -297,7 +352,7 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
         wp.get(0, bx_, by_);
     }
     const T he = wrap_pi<T>(L::atan2(by_ - ay_, bx_ - ax_) - yaw);         // :122-123
-    T steer = he + L::atan(G.k * sign * cte / (v + G.k_soft));             // :124-126
+    T steer = he + L::atan(L::div(G.k * sign * cte, v + G.k_soft));        // :124-126
     steer = steer < -G.max_steer ? -G.max_steer : steer;                   // :128 np.clip
     steer = steer > G.max_steer ? G.max_steer : steer;
     steer_out = steer;
@@ -327,6 +382,7 @@ struct CtrlState {
     T x_del, total, prev_vel, target, delta, tau;
     int idx;  // last target index (diagnostic)
     T cte;    // last crosstrack error (diagnostic)
+    int near = -1;  // nearest waypoint of the last update: prunes the next search (never changes its result)
 };
 
 // One controller update, drive.py:128-138, from the current vehicle state s[10];
@@ -335,7 +391,7 @@ template <typename T>
 __device__ __forceinline__ void controller_update(const CtrlGains<T> &G, const Waypoints<T> &wp, const T s[10],
                                                   T dt, CtrlState<T> &c, T &steer)
 {
-    stanley_control<T>(G, wp, s[8], s[9], s[7], s[0], steer, c.idx, c.cte);  // drive.py:129-130
+    stanley_control<T>(G, wp, s[8], s[9], s[7], s[0], steer, c.idx, c.cte, &c.near);  // drive.py:129-130
     long_control<T>(G, c.target, s[0], c.prev_vel, c.total, dt, c.tau);       // :131-133
     c.prev_vel = s[0];                                                        // :134
     c.x_del = G.filt_keep * c.x_del + G.filt_gain * steer;                    // :137

@@ -664,11 +664,9 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     const bool active = gid < n;
     const int64_t r = active ? gid : n - 1;
 
-    T s[10], ax, ay;
+    typename StepEngine<T>::State X;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) s[i] = state0[(int64_t)i * n + r];
-    ax = state0[10 * n + r];
-    ay = state0[11 * n + r];
+    for (int i = 0; i < 12; ++i) X.set(i, state0[(int64_t)i * n + r]);
     CtrlState<T> c;
     c.x_del = cstate0[r];
     c.total = cstate0[n + r];
@@ -693,7 +691,9 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     int until_update = (ctrl_every - phase % ctrl_every) % ctrl_every;   // steps until (phase + t) % ctrl_every == 0
     for (int t = 0; t < H; ++t) {
         if (until_update == 0) {               // wave-uniform; a countdown instead of a modulo per step
-            T steer_raw;
+            T steer_raw, s[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s[i] = X.get(i);
             controller_update<T>(G, w, s, h, c, steer_raw);
             until_update = ctrl_every;
         }
@@ -702,15 +702,25 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
         T sd[10];
         Outputs18<T> o18;
-        if (DATALOG) eng.template advance_diag<true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
-        else eng.template advance<true, CS>(P, s, ax, ay, delta, tq, P.mu, h);
+        if (DATALOG) {
+            T s[10], ax = X.get(10), ay = X.get(11);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s[i] = X.get(i);
+            eng.template advance_diag<true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) X.set(i, s[i]);
+            X.set(10, ax);
+            X.set(11, ay);
+        } else {
+            eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+        }
         if (DATALOG && active) {
             // written once, never read back by this kernel: streaming (non-temporal) stores
             T *row = datalog + (int64_t)t * 45 * n + r;
 #define VDYN_NT(idx, val) __builtin_nontemporal_store((T)(val), row + (int64_t)(idx) * n)
             VDYN_NT(0, (T)(phase + t) * h);                                       // drive.py:145
 #pragma unroll
-            for (int i = 0; i < 10; ++i) VDYN_NT(1 + i, s[i]);                    // :146
+            for (int i = 0; i < 10; ++i) VDYN_NT(1 + i, X.get(i));                // :146
 #pragma unroll
             for (int i = 0; i < 10; ++i) VDYN_NT(11 + i, sd[i]);                  // :147
             VDYN_NT(21, c.delta);                                                 // :148
@@ -724,9 +734,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         if (log != nullptr && active) {
             T *row = log + (int64_t)t * 16 * n + r;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) row[(int64_t)i * n] = s[i];
-            row[10 * n] = ax;
-            row[11 * n] = ay;
+            for (int i = 0; i < 12; ++i) row[(int64_t)i * n] = X.get(i);
             row[12 * n] = c.delta;
             row[13 * n] = c.tau;
             row[14 * n] = (T)c.idx;
@@ -735,9 +743,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     }
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) terminal[(int64_t)i * n + r] = s[i];
-        terminal[10 * n + r] = ax;
-        terminal[11 * n + r] = ay;
+        for (int i = 0; i < 12; ++i) terminal[(int64_t)i * n + r] = X.get(i);
         cstate[r] = c.x_del;
         cstate[n + r] = c.total;
         cstate[2 * n + r] = c.prev_vel;
