@@ -289,7 +289,50 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const Way
     int ce = best_i;
     T px, py;
     wp.get(best_i, px, py);
-    if (wp.seg != nullptr) {
+    if (sizeof(T) == 4 && wp.seg != nullptr) {
+        // fp32: wp.seg holds the CUMULATIVE arc length cum[i] = sum_{j <= i} |wp[j] - wp[j-1]| (waypoint_cumsum_kernel),
+        // and the walk becomes a search for the first i > best_i with total + cum[i] - cum[best_i] >= lookahead:
+        // a guess from the table's mean spacing, an 8-entry window around it, a bisection when the window
+        // misses.  The reference adds the segments one by one; the two sums differ by fp32 rounding only
+        // (167 dependent adds at 5 m / 3 cm: the chain this removes), which can move the index by one exactly
+        // where the fp32 sequential sum itself is within rounding of the boundary.  fp64 keeps the exact walk.
+        const int last = wp.W - 1;
+        if (total < G.lookahead && best_i < last) {
+            const T target = wp.seg_at(best_i) + (G.lookahead - total);
+            const T span = wp.seg_at(last);
+            int lo = best_i, hi = last;                          // invariant: cum[lo] < target; answer in (lo, hi]
+            const T per = (T)last / span;                         // waypoints per metre (inf / NaN: the bisection decides)
+            T gf = (T)best_i + (G.lookahead - total) * per;
+            gf = gf < (T)(best_i + 1) ? (T)(best_i + 1) : gf;
+            gf = gf > (T)last ? (T)last : gf;                     // NaN stays NaN -> int conversion clamps below
+            int g = (int)gf;
+            g = min(max(g, best_i + 1), last);
+            constexpr int kWin = 8;
+            const int w0 = min(max(g - kWin / 2, best_i + 1), max(last - kWin + 1, best_i + 1));
+            T cw[kWin];
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) cw[k] = wp.seg_at(min(w0 + k, last));
+            // window entries below the target raise lo, entries at or above it lower hi (cum is non-decreasing)
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const int i = min(w0 + k, last);
+                const bool below = cw[k] < target;
+                lo = below && i > lo ? i : lo;
+                hi = !below && i < hi && cw[k] == cw[k] ? i : hi;
+            }
+            while (__any(hi - lo > 1)) {                          // normally zero trips: the window bracketed the crossing
+                const int mid = (lo + hi) >> 1;
+                const T cm = wp.seg_at(mid);
+                const bool below = cm < target;
+                const bool act = hi - lo > 1;
+                lo = act && below ? mid : lo;
+                hi = act && !below ? mid : hi;
+            }
+            // cum[last] < target (the path ends before the lookahead distance): the reference stops at the last waypoint
+            ce = hi;
+        }
+        wp.get(ce, px, py);
+    } else if (wp.seg != nullptr) {
         // same sequential sum as the reference, sixteen precomputed segment lengths per trip.  The
         // running total never decreases (lengths are >= 0), so a trip whose LAST partial sum is
         // still short of the lookahead cannot contain the crossing: sixteen dependent adds and one

@@ -613,6 +613,33 @@ waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ 
     }
 }
 
+// fp32 controllers search the lookahead point on the CUMULATIVE arc length (vdyn_controls.hpp): turn the
+// segment lengths of waypoint_aux_kernel into running sums, in place.  One wave per table: every lane sums
+// its chunk, a wave scan gives the chunk offsets, a second pass writes the running sums.
+template <typename T, bool LDSIMG>
+__global__ void __launch_bounds__(64)
+waypoint_cumsum_kernel(int Wmax, int Pn, T *__restrict__ aux)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int64_t sj = LDSIMG ? 1 : Pn, sp = LDSIMG ? Wmax + 1 : 1;
+    T *seg = aux + (int64_t)p * sp;
+    const int chunk = (Wmax + 63) / 64;
+    const int j0 = lane * chunk, j1 = min(j0 + chunk, Wmax);
+    T sum = T(0);
+    for (int j = j0; j < j1; ++j) sum += seg[(int64_t)j * sj];
+    T incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    T run = incl - sum;                                             // exclusive offset of this lane's chunk
+    for (int j = j0; j < j1; ++j) {
+        run += seg[(int64_t)j * sj];
+        seg[(int64_t)j * sj] = run;
+    }
+}
+
 template <typename T>
 size_t waypoint_aux_len(int P, int Wmax, bool ldsimg)
 {
@@ -1289,6 +1316,12 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
                                a.Wmax, a.wcount, a.P, a.aux);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
+        if (sizeof(T) == 4) {                                   // fp32: cumulative arc length instead of segment lengths
+            if (lds) hipLaunchKernelGGL((waypoint_cumsum_kernel<T, true>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
+            else hipLaunchKernelGGL((waypoint_cumsum_kernel<T, false>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
+            e_ = hipGetLastError();
+            if (e_ != hipSuccess) return e_;
+        }
     }
 #define VDYN_CL2(CSV, LDSV, DLV)                                                                      \
     {                                                                                                 \
@@ -1337,6 +1370,11 @@ hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs
                            a.wcount, a.P, a.aux);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
+        if (sizeof(T) == 4) {
+            hipLaunchKernelGGL((waypoint_cumsum_kernel<T, false>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
+            e_ = hipGetLastError();
+            if (e_ != hipSuccess) return e_;
+        }
     }
     hipLaunchKernelGGL((controller_kernel<T>), dim3(grid), dim3(kBlock), 0, st, G, a.n, a.state0, a.cstate0,
                        a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.cstate, a.ctrl_out, (const T *)a.aux);
