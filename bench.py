@@ -548,7 +548,7 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
         lat = vm.plan_lattice(lat32[0], lat32[1], lat32[2], 25.0)
         _, traj = vm.rollout_spiral(s_p, lat["params"], HORIZON, torque=100.0, traj_stride=10)
         gi = lat["goal_index"].long()
-        return vm.select_best_rollout(traj, 7, obst32, torch.stack([lat32[0][gi], lat32[1][gi]]))
+        return vm.select_best_rollout(traj, 7, obst32, torch.stack([lat32[0][gi], lat32[1][gi]]), validity=lat["validity"])
 
     pipeline()
     t = timed_launches(pipeline, 3, torch)
@@ -568,14 +568,16 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     s_f, c_f = torch.from_numpy(s_f).to(dev), torch.from_numpy(c_f).to(dev)
     ids = torch.arange(Ef, dtype=torch.int32, device=dev)
     vmf = type(vm)(2.906, np.deg2rad(30), 1e-4, device=vm.device)
+    fleet_tables = (torch.zeros((Ef, 4096, 2), dtype=torch.float64, device=dev),
+                    torch.zeros((Ef,), dtype=torch.int32, device=dev))
 
     def frame():
         lat = vmf.plan_lattice(lat_in[0], lat_in[1], egof, 25.0)
         gi = lat["goal_index"].long()
         goal = torch.stack([lat_in[0][gi], lat_in[1][gi]])
-        _, best, _ = vmf.select_best_path(lat["paths"], obst, goal)
-        wp, wc = vmf.interpolate_waypoints(lat["paths"], best, 0.01, 4096)
-        return vmf.closed_loop(s_f, c_f, wp, 100, wcount=wc, path_id=ids)
+        _, best, _ = vmf.select_best_path(lat["paths"], obst, goal, validity=lat["validity"])
+        vmf.interpolate_waypoints(lat["paths"], best, 0.01, 4096, out=fleet_tables)   # an ego without a path keeps its table
+        return vmf.closed_loop(s_f, c_f, fleet_tables[0], 100, wcount=fleet_tables[1].clamp(min=1), path_id=ids)
 
     term_f, _ = frame()
     assert bool(torch.isfinite(term_f).all())

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define VDYN_ABI_VERSION 1
+#define VDYN_ABI_VERSION 2   /* 2: validity argument of vdyn_select_best_path_*, in/out tables of vdyn_interpolate_waypoints_* */
 
 enum {
     VDYN_OK = 0,
@@ -311,29 +311,39 @@ int vdyn_closed_loop_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64_t n, 
  *   HOST arrays of nc <= 8 doubles; P <= 64; goal [2][E].
  *   collision_in (nullable) [E][P]: flags the caller already has (1 = free); the check is then
  *   skipped and only select_best_path_index runs (its collision_check_array argument, :134).
- * -> collision_free [E][P] (1 = free), best_idx [E], best_score [E].                          */
+ *   validity (nullable) [E][P]: the `validity` output of vdyn_plan_lattice_*.  The reference drops
+ *   invalid spirals from its path list BEFORE the collision check and the selection
+ *   (local_planner.py:312-321,367-378): a path with validity 0 is absent -- never selectable, no
+ *   proximity penalty from it, collision_free = 0.  best_idx stays an index into all P paths (the
+ *   reference's best_index counts valid paths only: its value is the number of valid paths before
+ *   best_idx).
+ * -> collision_free [E][P] (1 = free), best_idx [E] (-1: none, the reference's None), best_score [E]. */
 int vdyn_select_best_path_f64_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *x,
                                   const double *y, const double *yaw, int64_t ego_stride, int64_t path_stride,
                                   int64_t point_stride, const double *obst, int32_t M, int32_t obst_per_ego,
                                   const double *circle_offsets, const double *circle_radii, int32_t nc,
                                   const double *goal, double weight, const int32_t *collision_in,
-                                  int32_t *collision_free, int32_t *best_idx, double *best_score, void *stream);
+                                  const int32_t *validity, int32_t *collision_free, int32_t *best_idx,
+                                  double *best_score, void *stream);
 int vdyn_select_best_path_f32_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const float *x,
                                   const float *y, const float *yaw, int64_t ego_stride, int64_t path_stride,
                                   int64_t point_stride, const float *obst, int32_t M, int32_t obst_per_ego,
                                   const double *circle_offsets, const double *circle_radii, int32_t nc,
                                   const float *goal, double weight, const int32_t *collision_in,
-                                  int32_t *collision_free, int32_t *best_idx, float *best_score, void *stream);
+                                  const int32_t *validity, int32_t *collision_free, int32_t *best_idx,
+                                  float *best_score, void *stream);
 int vdyn_select_best_path_f64_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *paths,
                                    const double *obst, int32_t M, int32_t obst_per_ego,
                                    const double *circle_offsets, const double *circle_radii, int32_t nc,
                                    const double *goal, double weight, const int32_t *collision_in,
-                                   int32_t *collision_free, int32_t *best_idx, double *best_score);
+                                   const int32_t *validity, int32_t *collision_free, int32_t *best_idx,
+                                   double *best_score);
 int vdyn_select_best_path_f32_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const float *paths,
                                    const float *obst, int32_t M, int32_t obst_per_ego,
                                    const double *circle_offsets, const double *circle_radii, int32_t nc,
                                    const float *goal, double weight, const int32_t *collision_in,
-                                   int32_t *collision_free, int32_t *best_idx, float *best_score);
+                                   const int32_t *validity, int32_t *collision_free, int32_t *best_idx,
+                                   float *best_score);
 
 /* ==== "next" row: lattice generation ========================================================
  * Replaces, for E egos at once, the planning cycle of LocalPlanner.MotionPlanner up to the
@@ -374,8 +384,11 @@ int vdyn_plan_lattice_f32_host(VdynHandle *h, int32_t E, const float *px, const 
 /* Replaces: the waypoint re-interpolation of local_planner.py:395-419 (INTERP_DISTANCE_RES =
  * 0.01, :19) that feeds StanleyController.update_waypoints: for every ego, path best_idx[e] of
  * paths [E][P][3][L] is resampled to `res` spacing.
- * -> wp_out [E][Wmax][2] (x, y), wcount [E] (0 when best_idx[e] < 0 or Wmax is too small): the
- *    waypoint tables vdyn_closed_loop_* / vdyn_controller_update_* take.                       */
+ * wp_out [E][Wmax][2] (x, y) and wcount [E] are IN / OUT: an ego with best_idx[e] < 0 (no selectable
+ * path: the reference's best_index None) keeps the table it had -- the reference goes on following
+ * _prev_best_path (local_planner.py:380-384) -- so pass the previous cycle's buffers back in (or
+ * zero-initialised ones on the first cycle).  wcount = 0 when Wmax is too small.  These are the
+ * waypoint tables vdyn_closed_loop_* / vdyn_controller_update_* take.                          */
 int vdyn_interpolate_waypoints_f64_dev(VdynHandle *h, int32_t E, int32_t P, int32_t L, const double *paths,
                                        const int32_t *best_idx, double res, int32_t Wmax, double *wp_out,
                                        int32_t *wcount, void *stream);

@@ -65,8 +65,8 @@ typedef struct OracleCtrlParams {
                                     long ego_stride, long path_stride, long point_stride,              \
                                     const REAL *obst, int M, long obst_ego_stride,                     \
                                     const double *offsets, const double *radii, int nc,                \
-                                    const REAL *goal, double weight, int *collision_free,              \
-                                    int *best_idx, REAL *best_score, int nthreads);                    \
+                                    const REAL *goal, double weight, const int *validity,              \
+                                    int *collision_free, int *best_idx, REAL *best_score, int nthreads); \
     int oracle_closest_index_##S(const REAL *px, const REAL *py, int n, REAL ex, REAL ey, REAL *len);   \
     int oracle_goal_index_##S(const REAL *px, const REAL *py, int n, REAL lookahead, REAL closest_len,  \
                               int closest_index);                                                       \

@@ -11,7 +11,7 @@ import os
 
 from ._build import LIB_PATH
 
-VDYN_ABI_VERSION = 1
+VDYN_ABI_VERSION = 2
 VDYN_OK, VDYN_ERR_ARG, VDYN_ERR_HIP, VDYN_ERR_NODEV, VDYN_ERR_OOM = 0, -1, -2, -3, -4
 VDYN_CTRL_PER_ROLLOUT, VDYN_CTRL_SHARED = 0, 1
 VDYN_OPT_LANES_PER_ROLLOUT = 1
@@ -85,10 +85,10 @@ for _s in ("f32", "f64"):
 
 for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_select_best_path_{_s}_dev"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64,
-                                                            _vp, _i32, _i32, _vp, _vp, _i32, _vp, _dbl, _vp, _vp,
+                                                            _vp, _i32, _i32, _vp, _vp, _i32, _vp, _dbl, _vp, _vp, _vp,
                                                             _vp, _vp, _vp])
     SIGNATURES[f"vdyn_select_best_path_{_s}_host"] = (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp,
-                                                             _vp, _i32, _vp, _dbl, _vp, _vp, _vp, _vp])
+                                                             _vp, _i32, _vp, _dbl, _vp, _vp, _vp, _vp, _vp])
 
 for _s in ("f32", "f64"):
     _pl = [_vp, _i32, _vp, _vp, _i32, _vp, _dbl, _dbl, _i32, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]

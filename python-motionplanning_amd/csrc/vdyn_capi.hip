@@ -731,8 +731,8 @@ int select_dev(VdynHandle *h, const vdyn::SelectArgs<T> &a, void *stream)
 template <typename T>
 int select_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, const T *obst, int32_t M,
                 int32_t obst_per_ego, const double *offsets, const double *radii, int32_t nc, const T *goal,
-                double weight, const int32_t *collision_in, int32_t *collision_free, int32_t *best_idx,
-                T *best_score)
+                double weight, const int32_t *collision_in, const int32_t *validity, int32_t *collision_free,
+                int32_t *best_idx, T *best_score)
 {
     if (!h) return VDYN_ERR_ARG;
     vdyn::SelectArgs<T> a;
@@ -748,7 +748,8 @@ int select_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, 
     const size_t i0 = s.in(paths, sizeof(T) * (size_t)E * P * 3 * L),
                  i1 = s.in(obst, sizeof(T) * 2 * (size_t)M * (obst_per_ego ? E : 1)),
                  i2 = s.in(goal, sizeof(T) * 2 * (size_t)E),
-                 i3 = s.in(collision_in, sizeof(int32_t) * (size_t)E * P);
+                 i3 = s.in(collision_in, sizeof(int32_t) * (size_t)E * P),
+                 i4 = s.in(validity, sizeof(int32_t) * (size_t)E * P);
     const size_t o0 = s.out(collision_free, sizeof(int32_t) * (size_t)E * P),
                  o1 = s.out(best_idx, sizeof(int32_t) * (size_t)E), o2 = s.out(best_score, sizeof(T) * (size_t)E);
     int rc = s.upload();
@@ -758,6 +759,7 @@ int select_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, 
     a.obst = s.dev<T>(i1, false);
     a.goal = s.dev<T>(i2, false);
     a.collision_in = s.dev<int>(i3, false);
+    a.validity = s.dev<int>(i4, false);
     a.collision_free = s.dev<int>(o0, true);
     a.best_idx = s.dev<int>(o1, true);
     a.best_score = s.dev<T>(o2, true);
@@ -851,10 +853,14 @@ int interp_host(VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, 
     if (E <= 0 || P <= 0 || L < 2 || Wmax < 2 || !paths || !best_idx || !wp_out || !wcount)
         return E == 0 ? VDYN_OK : interp_dev<T>(h, E, P, L, paths, best_idx, res, Wmax, wp_out, wcount, h->stream);
     Stage s(h);
-    const size_t i0 = s.in(paths, sizeof(T) * (size_t)E * P * 3 * L), i1 = s.in(best_idx, sizeof(int32_t) * (size_t)E);
-    const size_t o0 = s.out(wp_out, sizeof(T) * (size_t)E * Wmax * 2), o1 = s.out(wcount, sizeof(int32_t) * (size_t)E);
+    const size_t wpb = sizeof(T) * (size_t)E * Wmax * 2, wcb = sizeof(int32_t) * (size_t)E;
+    const size_t i0 = s.in(paths, sizeof(T) * (size_t)E * P * 3 * L), i1 = s.in(best_idx, sizeof(int32_t) * (size_t)E),
+                 i2 = s.in(wp_out, wpb), i3 = s.in(wcount, wcb);      // IN / OUT: egos without a path keep their table
+    const size_t o0 = s.out(wp_out, wpb), o1 = s.out(wcount, wcb);
     int rc = s.upload();
     if (rc) return rc;
+    VDYN_HIP(h, hipMemcpyAsync(s.dev<T>(o0, true), s.dev<T>(i2, false), wpb, hipMemcpyDeviceToDevice, h->stream));
+    VDYN_HIP(h, hipMemcpyAsync(s.dev<int>(o1, true), s.dev<int>(i3, false), wcb, hipMemcpyDeviceToDevice, h->stream));
     rc = interp_dev<T>(h, E, P, L, s.dev<T>(i0, false), s.dev<int>(i1, false), res, Wmax, s.dev<T>(o0, true),
                        s.dev<int>(o1, true), h->stream);
     if (rc) return rc;
@@ -985,26 +991,26 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
         VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *x, const T *y, const T *yaw,            \
         int64_t ego_stride, int64_t path_stride, int64_t point_stride, const T *obst, int32_t M,         \
         int32_t obst_per_ego, const double *circle_offsets, const double *circle_radii, int32_t nc,      \
-        const T *goal, double weight, const int32_t *collision_in, int32_t *collision_free,              \
-        int32_t *best_idx, T *best_score, void *stream)                                                                                    \
+        const T *goal, double weight, const int32_t *collision_in, const int32_t *validity,              \
+        int32_t *collision_free, int32_t *best_idx, T *best_score, void *stream)                         \
     {                                                                                                    \
         vdyn::SelectArgs<T> a;                                                                           \
         a.E = E; a.P = P; a.L = L; a.x = x; a.y = y; a.yaw = yaw; a.ego_stride = ego_stride;             \
         a.path_stride = path_stride; a.point_stride = point_stride; a.obst = obst; a.M = M;              \
         a.obst_ego_stride = obst_per_ego ? 2 * (int64_t)M : 0; a.offsets = circle_offsets;               \
         a.radii = circle_radii; a.nc = nc; a.goal = goal; a.weight = weight;                             \
-        a.collision_in = collision_in; a.collision_free = collision_free; a.best_idx = best_idx;         \
-        a.best_score = best_score;                                                                       \
+        a.collision_in = collision_in; a.validity = validity; a.collision_free = collision_free;         \
+        a.best_idx = best_idx; a.best_score = best_score;                                                \
         return select_dev<T>(h, a, stream);                                                              \
     }                                                                                                    \
     extern "C" int vdyn_select_best_path_##S##_host(                                                     \
         VdynHandle *h, int32_t E, int32_t P, int32_t L, const T *paths, const T *obst, int32_t M,        \
         int32_t obst_per_ego, const double *circle_offsets, const double *circle_radii, int32_t nc,      \
-        const T *goal, double weight, const int32_t *collision_in, int32_t *collision_free,              \
-        int32_t *best_idx, T *best_score)                                                                \
+        const T *goal, double weight, const int32_t *collision_in, const int32_t *validity,              \
+        int32_t *collision_free, int32_t *best_idx, T *best_score)                                       \
     {                                                                                                    \
         return select_host<T>(h, E, P, L, paths, obst, M, obst_per_ego, circle_offsets, circle_radii, nc, \
-                              goal, weight, collision_in, collision_free, best_idx, best_score);                       \
+                              goal, weight, collision_in, validity, collision_free, best_idx, best_score); \
     }
 
 #define VDYN_DEFINE_FLEET_ABI(S, T)                                                                      \

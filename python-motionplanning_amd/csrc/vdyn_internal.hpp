@@ -100,6 +100,7 @@ struct SelectArgs {
     const T *goal = nullptr;                               // [2][E]
     double weight = 0;
     const int *collision_in = nullptr;                     // nullable [E][P]: skip the check, use these flags
+    const int *validity = nullptr;                         // nullable [E][P]: 0 = path absent (dropped by the planner)
     int *collision_free = nullptr;                         // [E][P]
     int *best_idx = nullptr;                               // [E]
     T *best_score = nullptr;                               // [E]

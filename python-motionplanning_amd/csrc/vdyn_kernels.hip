@@ -841,12 +841,12 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
                         const T *__restrict__ yaw, int64_t ego_stride, int64_t path_stride, int64_t point_stride,
                         const T *__restrict__ obst, int M, int64_t obst_ego_stride, Circles<T> circ,
                         const T *__restrict__ goal, T weight, const int *__restrict__ collision_in,
-                        int *__restrict__ collision_free, int *__restrict__ best_idx,
-                        T *__restrict__ best_score, int chunk)
+                        const int *__restrict__ validity, int *__restrict__ collision_free,
+                        int *__restrict__ best_idx, T *__restrict__ best_score, int chunk)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *lds_ob = reinterpret_cast<T *>(smem_raw);
-    __shared__ int s_coll[kMaxPaths];
+    __shared__ int s_coll[kMaxPaths], s_valid[kMaxPaths];
     __shared__ T s_ex[kMaxPaths], s_ey[kMaxPaths];
     const int e = blockIdx.x;
     const T *ob = obst + (int64_t)e * obst_ego_stride;
@@ -854,6 +854,10 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
     if (threadIdx.x < kMaxPaths)
         s_coll[threadIdx.x] = (collision_in != nullptr && threadIdx.x < P)
                                   ? (collision_in[(int64_t)e * P + threadIdx.x] ? 0 : 1) : 0;
+    // validity (nullable [E][P]): spirals the planner dropped (local_planner.py:317-321) are ABSENT from the
+    // reference's path list -- never selectable and no contribution to anyone's proximity penalty
+    if (threadIdx.x < kMaxPaths)
+        s_valid[threadIdx.x] = threadIdx.x < P && (validity == nullptr || validity[(int64_t)e * P + threadIdx.x] != 0);
     if (collision_in != nullptr) M = 0;
 
     for (int m0 = 0; m0 < M; m0 += chunk) {
@@ -887,7 +891,7 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
                           (int64_t)(L - 1) * point_stride;
         s_ex[threadIdx.x] = x[o];
         s_ey[threadIdx.x] = y[o];
-        collision_free[(int64_t)e * P + threadIdx.x] = s_coll[threadIdx.x] ? 0 : 1;
+        collision_free[(int64_t)e * P + threadIdx.x] = (s_coll[threadIdx.x] || !s_valid[threadIdx.x]) ? 0 : 1;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -896,11 +900,12 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
         int bi = -1;
         for (int i = 0; i < P; ++i) {
             T score = T(INFINITY);                                                    // :190-191
+            if (!s_valid[i]) continue;
             if (!s_coll[i]) {
                 const T ax_ = s_ex[i] - gx, ay_ = s_ey[i] - gy;
                 score = Lib<T>::sqrt(ax_ * ax_ + ay_ * ay_);                          // :175
                 for (int j = 0; j < P; ++j) {
-                    if (j == i || !s_coll[j]) continue;
+                    if (j == i || !s_coll[j] || !s_valid[j]) continue;
                     const T bx_ = s_ex[i] - s_ex[j], by_ = s_ey[i] - s_ey[j];
                     score += weight * Lib<T>::sqrt(bx_ * bx_ + by_ * by_);            // :183-186
                 }
@@ -1007,7 +1012,8 @@ lattice_paths_kernel(int E, int P, const T *__restrict__ px, const T *__restrict
 
 // Waypoint re-interpolation (local_planner.py:395-419) of path best_idx[e] of every ego to `res`
 // spacing: one workgroup per ego; each lane owns one segment of the 48.
-//   wp_out [E][Wmax][2] (x, y), wcount [E]; an ego with best_idx < 0 or too many points gets 0.
+//   wp_out [E][Wmax][2] (x, y), wcount [E] are IN / OUT: an ego with best_idx < 0 keeps what they hold
+//   (its previous table); too many points for Wmax gives wcount 0.
 template <typename T>
 __global__ void __launch_bounds__(64)
 interpolate_waypoints_kernel(int E, int P, int L, const T *__restrict__ paths, const int *__restrict__ best_idx,
@@ -1016,7 +1022,9 @@ interpolate_waypoints_kernel(int E, int P, int L, const T *__restrict__ paths, c
     __shared__ int s_off[65];
     const int e = blockIdx.x, i = threadIdx.x;
     const int b = best_idx[e];
-    if (b < 0 || b >= P) { if (i == 0) wcount[e] = 0; return; }
+    // No selectable path (best_index is None): the reference keeps following the previous best path
+    // (local_planner.py:380-384), so this ego's table and count are left as the caller passed them in.
+    if (b < 0 || b >= P) return;
     const T *x = paths + ((int64_t)e * P + b) * 3 * L, *y = x + L;
     for (int base = 0; base < L - 1; base += 64) {      // L - 1 <= 64 segments per trip
         const int sgi = base + i;
@@ -1395,7 +1403,7 @@ hipError_t launch_select_best_path(const SelectArgs<T> &a, hipStream_t st)
     hipLaunchKernelGGL((select_best_path_kernel<T>), dim3((unsigned)a.E), dim3(kBlock),
                        (size_t)chunk * 2 * sizeof(T), st, a.E, a.P, a.L, a.x, a.y, a.yaw, a.ego_stride,
                        a.path_stride, a.point_stride, a.obst, a.M, a.obst_ego_stride, c, a.goal, (T)a.weight,
-                       a.collision_in, a.collision_free, a.best_idx, a.best_score, chunk);
+                       a.collision_in, a.validity, a.collision_free, a.best_idx, a.best_score, chunk);
     return hipGetLastError();
 }
 

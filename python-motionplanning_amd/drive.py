@@ -79,12 +79,11 @@ class Car:
         paths = lat["paths"][:, keep]
         gi = int(lat["goal_index"][0])
         goal = np.array([[self.px[gi]], [self.py[gi]]])
-        if len(keep):
-            _, best, _ = vm.select_best_path(paths, self.obstacles, goal, CIRCLE_OFFSETS, CIRCLE_RADII,
-                                             PATH_SELECT_WEIGHT)
-            best_index = None if best[0] < 0 else int(best[0])
-        else:
-            best_index = None
+        # the device treats invalid spirals as absent (vdyn_select_best_path_*'s validity argument); its index
+        # counts all NUM_PATHS paths, the reference's best_index the valid ones only
+        _, best, _ = vm.select_best_path(lat["paths"], self.obstacles, goal, CIRCLE_OFFSETS, CIRCLE_RADII,
+                                         PATH_SELECT_WEIGHT, validity=lat["validity"])
+        best_index = None if best[0] < 0 else int(np.searchsorted(keep, int(best[0])))
         if best_index is None:
             best_path = self._prev_best_path                          # local_planner.py:380-381
         else:

@@ -498,17 +498,19 @@ class VehicleModel:
 
     # ------------------------------------------------- collision check + best-path selection
     def select_best_path(self, paths, obstacles, goal, circle_offsets=(-1.0, 1.0, 3.0),
-                         circle_radii=(1.5, 1.5, 1.5), weight=10.0, collision_free=None):
+                         circle_radii=(1.5, 1.5, 1.5), weight=10.0, collision_free=None, validity=None):
         """collision_checker.py:32-117 + :134-203 for E egos x P paths x L points.
 
         ``paths [E][P][3][L]`` (rows x, y, yaw: the reference's path lists); ``obstacles
         [M][2]`` shared or ``[E][M][2]``; ``goal [2][E]``.  ``collision_free [E][P]`` given:
-        skip the check (select_best_path_index alone).  Returns ``collision_free [E][P]`` bool,
-        ``best_idx [E]`` (-1 = None) and ``best_score [E]``.  Defaults: drive.py:25-28.
+        skip the check (select_best_path_index alone).  ``validity [E][P]`` (``plan_lattice``'s output):
+        spirals the planner dropped (local_planner.py:312-321) are absent -- never selectable, no proximity
+        penalty from them.  Returns ``collision_free [E][P]`` bool, ``best_idx [E]`` (-1 = None; an index
+        into all P paths) and ``best_score [E]``.  Defaults: drive.py:25-28.
         torch CUDA tensors (e.g. ``plan_lattice``'s output) stay on the device."""
         if _is_torch_cuda(paths):
             return self._select_best_path_dev(paths, obstacles, goal, circle_offsets, circle_radii, weight,
-                                              collision_free)
+                                              collision_free, validity)
         pa = np.ascontiguousarray(paths)
         dtype = pa.dtype if pa.dtype in (np.float32, np.float64) else np.dtype(np.float64)
         pa = pa.astype(dtype, copy=False)
@@ -533,13 +535,17 @@ class VehicleModel:
         cin = None if collision_free is None else np.ascontiguousarray(collision_free, dtype=np.int32)
         if cin is not None and cin.shape != (E, P):
             raise ValueError("collision_free must be [E][P]")
+        val = None if validity is None else np.ascontiguousarray(validity, dtype=np.int32)
+        if val is not None and val.shape != (E, P):
+            raise ValueError("validity must be [E][P]")
         free, bi, bs = np.empty((E, P), np.int32), np.empty(E, np.int32), np.empty(E, dtype)
         self._handle(self.device).call(
             f"vdyn_select_best_path_{_suffix(dtype)}_host", E, P, L, _vp(pa), _vp(ob), M, int(per_ego), _vp(off),
-            _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(free), _vp(bi), _vp(bs))
+            _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(val), _vp(free), _vp(bi), _vp(bs))
         return free.astype(bool), bi, bs
 
-    def _select_best_path_dev(self, paths, obstacles, goal, circle_offsets, circle_radii, weight, collision_free):
+    def _select_best_path_dev(self, paths, obstacles, goal, circle_offsets, circle_radii, weight, collision_free,
+                              validity=None):
         be = _Backend(paths)
         pa = be.inp(paths)
         if pa.ndim != 4 or pa.shape[2] != 3:
@@ -557,17 +563,18 @@ class VehicleModel:
         if off.shape != rad.shape or off.ndim != 1 or not 1 <= off.size <= 8:
             raise ValueError("1..8 circle offsets / radii")
         cin = None if collision_free is None else be.inp(collision_free, shape=(E, P), int32=True)
+        val = None if validity is None else be.inp(validity, shape=(E, P), int32=True)
         free, bi, bs = be.out(E, P, int32=True), be.out(E, int32=True), be.out(E)
         esz, base = pa.element_size(), pa.data_ptr()
         self._handle(be.device_index(self.device)).call(
             f"vdyn_select_best_path_{be.suffix}_dev", E, P, L, C.c_void_p(base), C.c_void_p(base + L * esz),
             C.c_void_p(base + 2 * L * esz), P * 3 * L, 3 * L, 1, _vp(ob), int(ob.shape[-2]), int(per_ego), _vp(off),
-            _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(free), _vp(bi), _vp(bs),
+            _vp(rad), int(off.size), _vp(gl), float(weight), _vp(cin), _vp(val), _vp(free), _vp(bi), _vp(bs),
             *be.stream_args())
         return free.bool(), bi, bs
 
     def select_best_rollout(self, traj, paths_per_ego, obstacles, goal, circle_offsets=(-1.0, 1.0, 3.0),
-                            circle_radii=(1.5, 1.5, 1.5), weight=10.0):
+                            circle_radii=(1.5, 1.5, 1.5), weight=10.0, validity=None):
         """The same selection fed in place by the trajectory output of ``rollout`` on the GPU:
         ``traj [L][12][N]`` (torch CUDA tensor, N = E * paths_per_ego, ego-major), obstacles
         ``[M][2]`` and ``goal [2][E]`` tensors on the same device."""
@@ -586,13 +593,14 @@ class VehicleModel:
             raise ValueError("obstacles must be [M][2]")
         off = np.ascontiguousarray(circle_offsets, dtype=np.float64)
         rad = np.ascontiguousarray(circle_radii, dtype=np.float64)
+        val = None if validity is None else be.inp(validity, shape=(E, P), int32=True)
         free, bi, bs = be.out(E, P, int32=True), be.out(E, int32=True), be.out(E)
         esz = tr.element_size()
         base = tr.data_ptr()
         row = lambda r: C.c_void_p(base + r * N * esz)
         self._handle(be.device_index(self.device)).call(
             f"vdyn_select_best_path_{be.suffix}_dev", E, P, int(L), row(8), row(9), row(7), P, 1, 12 * N,
-            _vp(ob), int(ob.shape[0]), 0, _vp(off), _vp(rad), int(off.size), _vp(gl), float(weight), None,
+            _vp(ob), int(ob.shape[0]), 0, _vp(off), _vp(rad), int(off.size), _vp(gl), float(weight), None, _vp(val),
             _vp(free), _vp(bi), _vp(bs), *be.stream_args())
         return free, bi, bs
 
@@ -623,16 +631,33 @@ class VehicleModel:
         return dict(closest_index=ci, goal_index=gi, closest_len=cl, goal_set=gs, params=pr, paths=pa,
                     validity=val, cost=co)
 
-    def interpolate_waypoints(self, paths, best_idx, res=0.01, Wmax=4096):
+    def interpolate_waypoints(self, paths, best_idx, res=0.01, Wmax=4096, out=None):
         """local_planner.py:395-419 for E egos: ``paths [E][P][3][L]``, ``best_idx [E]`` ->
-        ``wp [E][Wmax][2]``, ``wcount [E]``: the tables ``closed_loop`` / ``controller_update`` take."""
+        ``wp [E][Wmax][2]``, ``wcount [E]``: the tables ``closed_loop`` / ``controller_update`` take.
+        An ego with ``best_idx < 0`` (no selectable path) keeps its previous table, as the reference keeps
+        ``_prev_best_path`` (local_planner.py:380-384): pass last cycle's ``(wp, wcount)`` as ``out`` and they
+        are updated in place; without ``out`` such an ego gets ``wcount = 0`` and an all-zero table."""
         be = _Backend(paths)
         pa = be.inp(paths)
         if pa.ndim != 4 or pa.shape[2] != 3 or pa.shape[3] < 2:
             raise ValueError("paths must be [E][P][3][L]")
         E, P, _, L = (int(v) for v in pa.shape)
         bi = be.inp(best_idx, shape=(E,), int32=True)
-        wp, wc = be.out(E, int(Wmax), 2), be.out(E, int32=True)
+        if out is not None:
+            wp, wc = out
+            if be.torch:
+                ok = _is_torch_cuda(wp) and _is_torch_cuda(wc) and wp.dtype == be.t_dtype and wp.is_contiguous() \
+                    and wc.is_contiguous() and str(wc.dtype) == "torch.int32"
+            else:
+                ok = isinstance(wp, np.ndarray) and isinstance(wc, np.ndarray) and wp.dtype == be.np_dtype and \
+                    wc.dtype == np.int32 and wp.flags.c_contiguous and wc.flags.c_contiguous
+            if not ok or tuple(wp.shape) != (E, int(Wmax), 2) or tuple(wc.shape) != (E,):
+                raise ValueError("out must be (wp [E][Wmax][2] of the call's dtype, wcount [E] int32), contiguous")
+        elif be.torch:
+            wp = be._t.zeros((E, int(Wmax), 2), dtype=be.t_dtype, device=be.device)
+            wc = be._t.zeros((E,), dtype=be._t.int32, device=be.device)
+        else:
+            wp, wc = np.zeros((E, int(Wmax), 2), be.np_dtype), np.zeros(E, np.int32)
         self._handle(be.device_index(self.device)).call(
             f"vdyn_interpolate_waypoints_{be.suffix}_{be.kind}", E, P, L, _vp(pa), _vp(bi), float(res), int(Wmax),
             _vp(wp), _vp(wc), *be.stream_args())

@@ -23,6 +23,8 @@ Sets:
   G8 config-3 shaped case (16 egos x 7 lattice paths x 200 steps)
   G12 lattice-driven rollouts: spiral parameters from the reference's PathOptimizer for 4 egos x 7
      lateral goals, the steering sequences they imply, terminal states from planar_model_RK4
+  G13 planning cycles in which the reference drops unreachable spirals (plan_paths validity), incl. "every
+     surviving path collides" and "no spiral survives": collision flags and best index over the survivors
   G9 closed-loop controller logs of the same 3-frame Car.drive run as G4 (world.path):
      the waypoint lists the planner handed to the Stanley controller, every
      stanley_control / long_control call (inputs -> outputs) and the steering filter
@@ -581,7 +583,91 @@ def g12():
           "clipped steps", int((np.abs(delta) >= MAX_STEER).sum()), "sf range", params[:, 2].min(), params[:, 2].max())
 
 
+def g13():
+    """Planning cycles in which the reference DROPS spirals: LocalPlanner.plan_paths on goal sets with
+    unreachable goals (end-point residual > 0.1 -> path_validity False, local_planner.py:312-321), then
+    transform_paths, CollisionChecker.collision_check on the surviving paths and select_best_path_index
+    (local_planner.py:366-384), incl. a cycle where every surviving path collides (best_index None) and one
+    where no spiral survives.  Stored per case for all 7 goals: the optimiser's parameters, the sampled and
+    transformed spiral (also of the dropped ones: optimize_spiral returns it either way), validity, and the
+    reference's collision flags / best index over the surviving paths."""
+    import scipy.integrate
+    import scipy.optimize
+    if not hasattr(scipy.integrate, "cumtrapz"):
+        scipy.integrate.cumtrapz = scipy.integrate.cumulative_trapezoid
+    import libs.vehicle_model.drive as drive
+    import libs.motionplanner.local_planner as lp
+    drive.os.system = lambda *_a, **_k: 0
+    planner = lp.LocalPlanner(drive.LOOKAHEAD, drive.NUM_PATHS, drive.PATH_OFFSET, drive.CIRCLE_OFFSETS,
+                              drive.CIRCLE_RADII, drive.PATH_SELECT_WEIGHT, drive.TIME_GAP, drive.A_MAX,
+                              drive.SLOW_SPEED, drive.STOP_LINE_BUFFER)
+    chk = planner._collision_checker
+    xs = []
+    orig = scipy.optimize.minimize
+
+    def minimize(fun, x0, **kw):
+        r = orig(fun, x0, **kw)
+        xs.append(np.array(r.x, float))
+        return r
+
+    rng = np.random.default_rng(13)
+    ego = [12.0, -4.0, 0.4, 20.0]
+
+    def lattice(head, ahead):
+        return [[ahead - (k - 3) * 2.0 * np.sin(head), (k - 3) * 2.0 * np.cos(head), head, 25.0] for k in range(7)]
+
+    cases = []
+    base = lattice(0.05, 30.0)
+    tight = [list(g) for g in base]
+    tight[0] = [2.0, -15.0, 2.0, 25.0]           # beyond what the bounded spiral reaches (residual 0.49 > 0.1)
+    tight[5] = [2.0, 6.0, -1.5, 25.0]            # residual 2.0
+    none_valid = [[1.0, 0.0, 3.0, 25.0], [-10.0, 0.0, 0.0, 25.0], [2.0, 6.0, -1.5, 25.0], [0.5, 3.0, 0.0, 25.0],
+                  [1.5, 1.5, -2.0, 25.0], [6.0, 0.0, 3.1, 25.0], [8.0, 20.0, -1.0, 25.0]]
+    scipy.optimize.minimize = minimize
+    try:
+        for name, goals, ob_mode in (("all_valid", base, "some"), ("two_dropped", tight, "some"),
+                                     ("two_dropped_all_blocked", tight, "all"), ("two_dropped_free", tight, "none"),
+                                     ("none_valid", none_valid, "some")):
+            k0 = len(xs)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sampled = [planner._path_optimizer.optimize_spiral(g[0], g[1], g[2]) for g in goals]
+                params = np.array(xs[k0:k0 + 7])
+                paths, validity = planner.plan_paths(goals)               # the reference's own filtering
+            assert len(paths) == sum(validity)
+            all_t = lp.transform_paths(sampled, ego)                       # every spiral, transformed (49 points each)
+            kept_t = lp.transform_paths(paths, ego)
+            ends = np.array([[p_[0][-1], p_[1][-1]] for p_ in kept_t]) if kept_t else np.zeros((0, 2))
+            if ob_mode == "none" or not len(ends):
+                obst = np.array([[500.0, 500.0], [501.0, 500.0]])
+            elif ob_mode == "all":
+                obst = np.concatenate([e + rng.normal(0, 0.2, (4, 2)) for e in ends])
+            else:
+                obst = np.concatenate([e + rng.normal(0, 0.2, (4, 2)) for e in ends[::2]])
+            flags = [bool(chk.collision_check(list(p_), obst)) for p_ in kept_t]
+            goal_state = [ego[0] + 30.0 * np.cos(ego[2]), ego[1] + 30.0 * np.sin(ego[2]), 25.0]
+            best = chk.select_best_path_index(kept_t, flags, goal_state)
+            cases.append(dict(name=name, goals=np.array(goals), params=params, validity=np.array(validity, bool),
+                              paths=np.array([[p_[0], p_[1], p_[2][:49]] for p_ in all_t]), obstacles=obst,
+                              free_kept=np.array(flags, bool), best_kept=-1 if best is None else int(best),
+                              goal=np.array(goal_state[:2])))
+            print("G13", name, "validity", np.array(validity, int), "free (kept)", np.array(flags, int), "best (kept)", best)
+    finally:
+        scipy.optimize.minimize = orig
+    M = max(len(c["obstacles"]) for c in cases)
+    np.savez_compressed(
+        os.path.join(HERE, "g13_dropped_spirals.npz"), names=np.array([c["name"] for c in cases]),
+        ego=np.array(ego), goals=np.array([c["goals"] for c in cases]), params=np.array([c["params"] for c in cases]),
+        validity=np.array([c["validity"] for c in cases]), paths=np.array([c["paths"] for c in cases]),
+        obstacles=np.array([np.concatenate([c["obstacles"], np.full((M - len(c["obstacles"]), 2), 900.0)]) for c in cases]),
+        free_full=np.array([np.where(c["validity"], np.isin(np.arange(7), np.flatnonzero(c["validity"])[c["free_kept"]])
+                                     if c["validity"].any() else False, False) for c in cases]),
+        best_kept=np.array([c["best_kept"] for c in cases]), goal=np.array([c["goal"] for c in cases]),
+        circle_offsets=np.array(drive.CIRCLE_OFFSETS, float), circle_radii=np.array(drive.CIRCLE_RADII, float),
+        weight=np.float64(drive.PATH_SELECT_WEIGHT))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -675,6 +675,21 @@ def test_g11_lattice_generation(gpu_vm, oracle):
         assert np.abs(wp[f, :wc[f]] - g9["waypoints"][f, :wc[f], :2]).max() <= 1e-11
     wp2, wc2 = vm.interpolate_waypoints(o["paths"], np.array([-1, 2, 6], np.int32), float(res), 1000)
     assert wc2[0] == 0 and wc2[1] == 0 and wc2[2] == 0                  # none selected / table too small
+    assert not wp2[0].any(), "an ego without a path and without a previous table gets zeros, never uninitialised memory"
+    # the reference keeps following _prev_best_path when best_index is None (local_planner.py:380-384):
+    # with last cycle's tables passed back in, ego 0 keeps its table, egos 1 and 2 get their new ones
+    prev_wp, prev_wc = wp.copy(), wc.copy()
+    wp3, wc3 = vm.interpolate_waypoints(o["paths"], np.array([-1, 2, 6], np.int32), float(res), 4096, out=(wp, wc))
+    assert wp3 is wp and wc3 is wc
+    assert wc[0] == prev_wc[0] and np.array_equal(wp[0], prev_wp[0])
+    want1, wantc = vm.interpolate_waypoints(o["paths"], np.array([0, 2, 6], np.int32), float(res), 4096)
+    assert np.array_equal(wc[1:], wantc[1:]) and np.array_equal(wp[1, :wc[1]], want1[1, :wc[1]])
+    import torch
+    dev = torch.device("cuda:0")
+    twp, twc = torch.from_numpy(prev_wp).to(dev), torch.from_numpy(prev_wc).to(dev)
+    vm.interpolate_waypoints(torch.from_numpy(o["paths"]).to(dev), torch.tensor([-1, 2, 6], dtype=torch.int32, device=dev),
+                             float(res), 4096, out=(twp, twc))
+    assert np.array_equal(twp.cpu().numpy()[0], prev_wp[0]) and np.array_equal(twc.cpu().numpy(), wc)
 
 
 def test_closest_index_ties_and_edges(gpu_vm, oracle):
@@ -833,7 +848,7 @@ def test_widened_entry_points_argument_errors_and_empty_batches(gpu_vm, pkg):
                None, None, None, None)                                   # null buffers
     with pytest.raises(pkg.VdynError):
         h.call("vdyn_select_best_path_f64_host", 2, 65, 10, None, None, 0, 0, None, None, 3, None, 1.0, None, None,
-               None, None)                                               # more than 64 paths
+               None, None, None)                                         # more than 64 paths
     with pytest.raises(pkg.VdynError):
         h.call("vdyn_plan_lattice_f64_host", 3, None, None, 1, None, 25.0, 30.0, 7, 2.0, None, None, None, None,
                None, None, None, None, None)                             # nwp < 2

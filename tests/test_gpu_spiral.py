@@ -127,3 +127,44 @@ def test_plan_rollout_select_pipeline_on_device(gpu_vm, oracle):
     assert np.array_equal(free.cpu().numpy().astype(bool), ofree.astype(bool))
     assert np.array_equal(best.cpu().numpy(), obest)
     assert (free.cpu().numpy().sum(axis=1) < P).any(), "the obstacles must block some rollouts for the test to mean anything"
+
+
+def test_g13_selection_with_dropped_spirals(gpu_vm, oracle):
+    """The reference drops unreachable spirals before the collision check and the selection
+    (local_planner.py:312-321,366-384): vdyn_select_best_path_*'s validity argument, against the reference's
+    own planning cycles (G13), incl. 'every surviving path collides' and 'no spiral survives' (best -1), on
+    host and device pointers, fp64 and fp32; and interpolate_waypoints keeping the previous table then."""
+    import torch
+    g = load_golden("g13_dropped_spirals.npz")
+    vm = gpu_vm(1e-3)
+    n = len(g["names"])
+    goal = g["goal"].T.copy()
+    keep = [np.flatnonzero(v) for v in g["validity"]]
+    want = np.array([-1 if b < 0 else keep[i][b] for i, b in enumerate(g["best_kept"])])
+    args = (g["circle_offsets"], g["circle_radii"], float(g["weight"]))
+    free, bi, bs = vm.select_best_path(g["paths"], g["obstacles"], goal, *args, validity=g["validity"])
+    assert np.array_equal(free, g["free_full"]) and np.array_equal(bi, want)
+    assert want.tolist()[2] == -1 and want.tolist()[4] == -1 and np.isinf(bs[[2, 4]]).all()
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ft, bt, _ = vm.select_best_path(t(g["paths"]), t(g["obstacles"]), t(goal), *args,
+                                    validity=t(g["validity"].astype(np.int32)))
+    assert np.array_equal(ft.cpu().numpy(), g["free_full"]) and np.array_equal(bt.cpu().numpy(), want)
+    f32, b32, _ = vm.select_best_path(g["paths"].astype(np.float32), g["obstacles"].astype(np.float32),
+                                      goal.astype(np.float32), *args, validity=g["validity"])
+    assert np.array_equal(f32, g["free_full"]) and np.array_equal(b32, want)
+    # the oracle agrees case by case (scores too)
+    for i in range(n):
+        of, ob, os_ = oracle.select_best_path(g["paths"][i][None], g["obstacles"][i], goal[:, i:i + 1], *args,
+                                              validity=g["validity"][i][None])
+        assert ob[0] == bi[i] and (np.isinf(bs[i]) if ob[0] < 0 else abs(os_[0] - bs[i]) <= 1e-9)
+    # an ego without a selectable path keeps the Stanley table of the previous cycle
+    wp, wc = vm.interpolate_waypoints(g["paths"], np.array([3, 1, 1, 2, 3], np.int32), 0.01, 4096)
+    before = (wp.copy(), wc.copy())
+    vm.interpolate_waypoints(g["paths"], bi.astype(np.int32), 0.01, 4096, out=(wp, wc))
+    for i in range(n):
+        if want[i] < 0:
+            assert wc[i] == before[1][i] and np.array_equal(wp[i], before[0][i])
+        else:
+            one, onec = vm.interpolate_waypoints(g["paths"][i:i + 1], bi[i:i + 1].astype(np.int32), 0.01, 4096)
+            assert wc[i] == onec[0] and np.array_equal(wp[i, :wc[i]], one[0, :onec[0]])

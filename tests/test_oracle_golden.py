@@ -333,3 +333,29 @@ def test_g12_spiral_rollouts_oracle_vs_reference(oracle):
     _, d2 = oracle.rollout_spiral(p, g["state0"], g["params"], H, dt, max_steer=lim, torque=tq, return_delta=True)
     assert np.abs(d2).max() <= lim and (np.abs(d2) == lim).any()
     assert np.abs(d2 - np.clip(g["delta"], -lim, lim)).max() <= 1e-15
+
+
+def _g13_expected_full_index(validity, best_kept):
+    """The reference's best_index counts the surviving paths only (local_planner.py:312-321,378)."""
+    keep = np.flatnonzero(validity)
+    return -1 if best_kept < 0 else int(keep[best_kept])
+
+
+def test_g13_selection_with_dropped_spirals_oracle_vs_reference(oracle):
+    g = load_golden("g13_dropped_spirals.npz")
+    assert list(g["names"]) == ["all_valid", "two_dropped", "two_dropped_all_blocked", "two_dropped_free", "none_valid"]
+    assert g["validity"].sum(axis=1).tolist() == [7, 5, 5, 5, 0]
+    for i in range(len(g["names"])):
+        free, bi, _ = oracle.select_best_path(g["paths"][i][None], g["obstacles"][i], g["goal"][i][:, None],
+                                              g["circle_offsets"], g["circle_radii"], float(g["weight"]),
+                                              validity=g["validity"][i][None])
+        assert np.array_equal(free[0], g["free_full"][i]), g["names"][i]
+        assert bi[0] == _g13_expected_full_index(g["validity"][i], int(g["best_kept"][i])), g["names"][i]
+    # ignoring validity is NOT the reference's result: a dropped spiral would be selectable / would add a penalty
+    i = 3                                                                       # two_dropped_free: nothing collides
+    _, bi_all, _ = oracle.select_best_path(g["paths"][i][None], g["obstacles"][i], g["goal"][i][:, None],
+                                           g["circle_offsets"], g["circle_radii"], float(g["weight"]))
+    free_v, _, _ = oracle.select_best_path(g["paths"][i][None], g["obstacles"][i], g["goal"][i][:, None],
+                                           g["circle_offsets"], g["circle_radii"], float(g["weight"]),
+                                           validity=g["validity"][i][None])
+    assert free_v[0].sum() == 5 and bi_all[0] >= 0

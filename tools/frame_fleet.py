@@ -39,7 +39,7 @@ def main():
         lat = vm.plan_lattice(gx, gy, egof, 25.0)
         gi = lat["goal_index"].long()
         goal = torch.stack([gx[gi], gy[gi]])
-        _, best, _ = vm.select_best_path(lat["paths"], obst, goal)
+        _, best, _ = vm.select_best_path(lat["paths"], obst, goal, validity=lat["validity"])
         wp, wc = vm.interpolate_waypoints(lat["paths"], best, 0.01, 4096)
         return vm.closed_loop(s_f, c_f, wp, 100, wcount=wc, path_id=ids)
 
