@@ -402,6 +402,38 @@ int vdyn_interpolate_waypoints_f32_host(VdynHandle *h, int32_t E, int32_t P, int
                                         const int32_t *best_idx, double res, int32_t Wmax, float *wp_out,
                                         int32_t *wcount);
 
+/* ==== diagnostics =============================================================================
+ * Per-lane non-finite status of a [rows][n] array (terminal states, trajectories ...): status[i] = 1 when
+ * any row of column i is inf or NaN.  The reference propagates inf / NaN and NumPy raises a RuntimeWarning
+ * (division by a zero wheel speed, vehicle_model.py:284-293); this is the batched counterpart of that
+ * warning.  count (nullable, HOST int64): number of flagged lanes (the _dev form then synchronises).   */
+int vdyn_nonfinite_lanes_f64_dev(VdynHandle *h, int32_t rows, int64_t n, const double *x, int32_t *status,
+                                 int64_t *count, void *stream);
+int vdyn_nonfinite_lanes_f32_dev(VdynHandle *h, int32_t rows, int64_t n, const float *x, int32_t *status,
+                                 int64_t *count, void *stream);
+int vdyn_nonfinite_lanes_f64_host(VdynHandle *h, int32_t rows, int64_t n, const double *x, int32_t *status,
+                                  int64_t *count);
+int vdyn_nonfinite_lanes_f32_host(VdynHandle *h, int32_t rows, int64_t n, const float *x, int32_t *status,
+                                  int64_t *count);
+
+/* Device self-test of the bounded-range elementary functions the FAST step is built from
+ * (csrc/vdyn_fastmath.hpp, csrc/vdyn_packed.hpp): evaluates function `fn` on x [n] (with the scalar
+ * parameter `c` where one applies) -> out0 [n], out1 [n] (second result, or untouched).
+ *   fn 0 atan_rcp(x, 1/x)          1 sin_0_pi(x)           2 sin_mid(x)        3 sincos_mid(x) -> (sin, cos)
+ *      4 sincos_kernel(x) -> (sin, cos)        [scalar forms, fp32 and fp64]
+ *   fp32 only, the packed step's own forms:
+ *      5 sin(c atan(x)), x >= 0, 0 <= c <= 2 (cosine form)   6 sincos of an unwrapped yaw -> (sin, cos)
+ *      7 small stage rotation -> (sin, cos)     8 steering sincos kernel -> (sin, cos)
+ * tests/test_gpu_fastmath.py holds each to its stated accuracy against float64 libm.                  */
+int vdyn_fastmath_eval_f32_dev(VdynHandle *h, int32_t fn, int64_t n, const float *x, double c, float *out0,
+                               float *out1, void *stream);
+int vdyn_fastmath_eval_f64_dev(VdynHandle *h, int32_t fn, int64_t n, const double *x, double c, double *out0,
+                               double *out1, void *stream);
+int vdyn_fastmath_eval_f32_host(VdynHandle *h, int32_t fn, int64_t n, const float *x, double c, float *out0,
+                                float *out1);
+int vdyn_fastmath_eval_f64_host(VdynHandle *h, int32_t fn, int64_t n, const double *x, double c, double *out0,
+                                double *out1);
+
 /* ==== multi-GPU exchange of terminal blocks without a collective kernel ====================
  * The path's only exchange step (north_star: "all-gather ... of final trajectories only") moves one
  * small block per rank ([12][n_local] fp32: 393 KB at 8192 rollouts, 3.1 MB at 65536).  RCCL does it

@@ -74,6 +74,12 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_rollout_spiral_{_s}_dev"] = (_int, _rs + [_vp])
     SIGNATURES[f"vdyn_rollout_spiral_{_s}_host"] = (_int, _rs)
 
+for _s in ("f32", "f64"):
+    SIGNATURES[f"vdyn_nonfinite_lanes_{_s}_dev"] = (_int, [_vp, _i32, _i64, _vp, _vp, C.POINTER(_i64), _vp])
+    SIGNATURES[f"vdyn_nonfinite_lanes_{_s}_host"] = (_int, [_vp, _i32, _i64, _vp, _vp, C.POINTER(_i64)])
+    SIGNATURES[f"vdyn_fastmath_eval_{_s}_dev"] = (_int, [_vp, _i32, _i64, _vp, _dbl, _vp, _vp, _vp])
+    SIGNATURES[f"vdyn_fastmath_eval_{_s}_host"] = (_int, [_vp, _i32, _i64, _vp, _dbl, _vp, _vp])
+
 _gp = C.POINTER(VdynCtrlGains)
 for _s in ("f32", "f64"):
     _cu = [_vp, _gp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _dbl, _vp, _vp]

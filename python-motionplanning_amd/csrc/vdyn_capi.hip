@@ -24,6 +24,7 @@ struct VdynHandle {
     size_t d_fleet_bytes = 0;
     void *d_aux = nullptr;          // controllers' auxiliary waypoint tables (segment lengths, bounding circles)
     size_t d_aux_bytes = 0;
+    void *d_count = nullptr;        // one counter (vdyn_nonfinite_lanes_*)
     void *d_cand = nullptr;         // MPC candidate table with the steering angles' (sin, cos) per entry
     size_t d_cand_bytes = 0;
     hipStream_t copy_stream = nullptr;   // peer exchange (vdyn_xchg_*): copies run here, beside the compute stream
@@ -169,6 +170,7 @@ void vdyn_destroy(VdynHandle *h)
     if (h->d_fleet) (void)hipFree(h->d_fleet);
     if (h->d_aux) (void)hipFree(h->d_aux);
     if (h->d_cand) (void)hipFree(h->d_cand);
+    if (h->d_count) (void)hipFree(h->d_count);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -342,6 +344,45 @@ int rollout_spiral_dev(VdynHandle *h, int64_t n, int32_t H, const T *state0, con
     VDYN_HIP(h, hipSetDevice(h->device));
     VDYN_HIP(h, vdyn::launch_rollout_spiral<T>(h->p, n, H, state0, spiral, wheelbase, tan_max, torque, dt, mu4,
                                                terminal, traj, traj_stride, (hipStream_t)stream));
+    return VDYN_OK;
+}
+
+template <typename T>
+int nonfinite_dev(VdynHandle *h, int32_t rows, int64_t n, const T *x, int32_t *status, int64_t *count, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (rows <= 0 || n < 0) return h->fail(VDYN_ERR_ARG, "nonfinite_lanes: need rows > 0, n >= 0");
+    if (count) *count = 0;
+    if (n == 0) return VDYN_OK;
+    if (!x || !status) return h->fail(VDYN_ERR_ARG, "nonfinite_lanes: null buffer");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    unsigned long long *dcount = nullptr;
+    if (count) {
+        if (!h->d_count) {
+            if (hipMalloc(&h->d_count, sizeof(unsigned long long)) != hipSuccess) return h->fail(VDYN_ERR_OOM, "nonfinite_lanes: allocation failed");
+        }
+        dcount = static_cast<unsigned long long *>(h->d_count);
+        VDYN_HIP(h, hipMemsetAsync(dcount, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    }
+    VDYN_HIP(h, vdyn::launch_nonfinite_lanes<T>(rows, n, x, status, dcount, (hipStream_t)stream));
+    if (count) {
+        unsigned long long c = 0;
+        VDYN_HIP(h, hipMemcpyAsync(&c, dcount, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        VDYN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+        *count = (int64_t)c;
+    }
+    return VDYN_OK;
+}
+
+template <typename T>
+int fastmath_dev(VdynHandle *h, int32_t fn, int64_t n, const T *x, double c, T *out0, T *out1, void *stream)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (fn < 0 || fn > (sizeof(T) == 4 ? 8 : 4) || n < 0) return h->fail(VDYN_ERR_ARG, "fastmath_eval: unknown function or n < 0");
+    if (n == 0) return VDYN_OK;
+    if (!x || !out0) return h->fail(VDYN_ERR_ARG, "fastmath_eval: null buffer");
+    VDYN_HIP(h, hipSetDevice(h->device));
+    VDYN_HIP(h, vdyn::launch_fastmath_eval<T>(fn, n, x, c, out0, out1, (hipStream_t)stream));
     return VDYN_OK;
 }
 
@@ -595,6 +636,36 @@ int rollout_spiral_host(VdynHandle *h, int64_t n, int32_t H, const T *state0, co
     if (rc) return rc;
     rc = rollout_spiral_dev<T>(h, n, H, s.dev<T>(i0, false), s.dev<T>(i1, false), wheelbase, max_steer, torque, dt, mu4,
                                s.dev<T>(o0, true), s.dev<T>(o1, true), traj_stride, h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+int nonfinite_host(VdynHandle *h, int32_t rows, int64_t n, const T *x, int32_t *status, int64_t *count)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (rows <= 0 || n <= 0 || !x || !status) return nonfinite_dev<T>(h, rows, n, x, status, count, h->stream);
+    Stage s(h);
+    const size_t i0 = s.in(x, sizeof(T) * (size_t)rows * (size_t)n);
+    const size_t o0 = s.out(status, sizeof(int32_t) * (size_t)n);
+    int rc = s.upload();
+    if (rc) return rc;
+    rc = nonfinite_dev<T>(h, rows, n, s.dev<T>(i0, false), s.dev<int32_t>(o0, true), count, h->stream);
+    if (rc) return rc;
+    return s.download();
+}
+
+template <typename T>
+int fastmath_host(VdynHandle *h, int32_t fn, int64_t n, const T *x, double c, T *out0, T *out1)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (n <= 0 || !x || !out0) return fastmath_dev<T>(h, fn, n, x, c, out0, out1, h->stream);
+    Stage s(h);
+    const size_t i0 = s.in(x, sizeof(T) * (size_t)n);
+    const size_t o0 = s.out(out0, sizeof(T) * (size_t)n), o1 = s.out(out1, sizeof(T) * (size_t)n);
+    int rc = s.upload();
+    if (rc) return rc;
+    rc = fastmath_dev<T>(h, fn, n, s.dev<T>(i0, false), c, s.dev<T>(o0, true), s.dev<T>(o1, true), h->stream);
     if (rc) return rc;
     return s.download();
 }
@@ -1088,8 +1159,32 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
                                       traj, traj_stride);                                                \
     }
 
+#define VDYN_DEFINE_DIAG_ABI(S, T)                                                                       \
+    extern "C" int vdyn_nonfinite_lanes_##S##_dev(VdynHandle *h, int32_t rows, int64_t n, const T *x,    \
+                                                  int32_t *status, int64_t *count, void *stream)         \
+    {                                                                                                    \
+        return nonfinite_dev<T>(h, rows, n, x, status, count, stream);                                   \
+    }                                                                                                    \
+    extern "C" int vdyn_nonfinite_lanes_##S##_host(VdynHandle *h, int32_t rows, int64_t n, const T *x,   \
+                                                   int32_t *status, int64_t *count)                      \
+    {                                                                                                    \
+        return nonfinite_host<T>(h, rows, n, x, status, count);                                          \
+    }                                                                                                    \
+    extern "C" int vdyn_fastmath_eval_##S##_dev(VdynHandle *h, int32_t fn, int64_t n, const T *x, double c, \
+                                                T *out0, T *out1, void *stream)                          \
+    {                                                                                                    \
+        return fastmath_dev<T>(h, fn, n, x, c, out0, out1, stream);                                      \
+    }                                                                                                    \
+    extern "C" int vdyn_fastmath_eval_##S##_host(VdynHandle *h, int32_t fn, int64_t n, const T *x, double c, \
+                                                 T *out0, T *out1)                                       \
+    {                                                                                                    \
+        return fastmath_host<T>(h, fn, n, x, c, out0, out1);                                             \
+    }
+
 VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
+VDYN_DEFINE_DIAG_ABI(f32, float)
+VDYN_DEFINE_DIAG_ABI(f64, double)
 VDYN_DEFINE_SPIRAL_ABI(f32, float)
 VDYN_DEFINE_SPIRAL_ABI(f64, double)
 VDYN_DEFINE_LATTICE_ABI(f32, float)

@@ -5,8 +5,8 @@
 // arguments are structurally bounded, so each function below is a short
 // straight-line polynomial plus at most one hardware reciprocal.
 //
-// Accuracy (checked by tools/fit_polys.py against float64 libm, and on the GPU
-// by tests/test_gpu_parity.py::test_fastmath_accuracy): <= 2 ulp each.
+// Accuracy: <= 2 ulp each -- checked at fitting time by tools/fit_polys.py against float64 libm and ON
+// THE DEVICE by tests/test_gpu_fastmath.py (dense grids through vdyn_fastmath_eval_*, include/vdyn.h).
 // Coefficients: tools/fit_polys.py (Lawson minimax fits, rounded to float).
 #pragma once
 #include <hip/hip_runtime.h>

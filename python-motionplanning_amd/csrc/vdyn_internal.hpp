@@ -50,6 +50,11 @@ template <typename T>
 int fleet_table_len(int V);
 
 template <typename T>
+hipError_t launch_nonfinite_lanes(int rows, int64_t n, const T *x, int *status, unsigned long long *count, hipStream_t st);
+template <typename T>
+hipError_t launch_fastmath_eval(int fn, int64_t n, const T *x, double c, T *out0, T *out1, hipStream_t st);
+
+template <typename T>
 hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, const T *ctrl12,
                                const T *acc_prev, T *state_dot, T *aux, T *outputs, T *acc,
                                hipStream_t st);

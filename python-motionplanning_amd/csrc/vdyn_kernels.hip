@@ -1068,6 +1068,91 @@ interpolate_waypoints_kernel(int E, int P, int L, const T *__restrict__ paths, c
     }
 }
 
+// Per-lane non-finite flag of a [rows][n] array (+ a count).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+nonfinite_lanes_kernel(int rows, int64_t n, const T *__restrict__ x, int *__restrict__ status,
+                       unsigned long long *__restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        for (int r = 0; r < rows; ++r) {
+            const T v = x[(int64_t)r * n + i];
+            bad = bad || !(abs_t(v) <= (sizeof(T) == 4 ? (T)3.4028234663852886e38 : (T)1.7976931348623157e308));
+        }
+        status[i] = bad ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(bad);
+    if (count != nullptr && (threadIdx.x & 63) == 0 && m != 0) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+// Device self-test of the elementary functions (include/vdyn.h, vdyn_fastmath_eval_*).
+template <typename T> struct FmSel;
+template <> struct FmSel<float> {
+    static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
+    static __device__ __forceinline__ float atan_rcp(float x, float ix) { return fm::atan_rcp(x, ix); }
+    static __device__ __forceinline__ float sin_0_pi(float x) { return fm::sin_0_pi(x); }
+    static __device__ __forceinline__ float sin_mid(float x) { return fm::sin_mid(x); }
+    static __device__ __forceinline__ void sincos_mid(float x, float *s, float *c) { fm::sincos_mid(x, s, c); }
+    static __device__ __forceinline__ void sincos_kernel(float x, float *s, float *c) { fm::sincos_kernel(x, s, c); }
+};
+template <> struct FmSel<double> {
+    static __device__ __forceinline__ double rcp(double x) { return fm64::rcp(x); }
+    static __device__ __forceinline__ double atan_rcp(double x, double ix) { return fm64::atan_rcp(x, ix); }
+    static __device__ __forceinline__ double sin_0_pi(double x) { return fm64::sin_0_pi(x); }
+    static __device__ __forceinline__ double sin_mid(double x) { return fm64::sin_mid(x); }
+    static __device__ __forceinline__ void sincos_mid(double x, double *s, double *c) { fm64::sincos_mid(x, s, c); }
+    static __device__ __forceinline__ void sincos_kernel(double x, double *s, double *c) { fm64::sincos_kernel(x, s, c); }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, T *__restrict__ out0, T *__restrict__ out1)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    PkConsts K;
+    K.init();
+    if (i >= n) return;
+    const T v = x[i];
+    T a = T(0), b = T(0);
+    bool two = false;
+    using F = FmSel<T>;
+    switch (fn) {
+    case 0: a = F::atan_rcp(v, F::rcp(v)); break;
+    case 1: a = F::sin_0_pi(v); break;
+    case 2: a = F::sin_mid(v); break;
+    case 3: F::sincos_mid(v, &a, &b); two = true; break;
+    case 4: F::sincos_kernel(v, &a, &b); two = true; break;
+    default:
+        if (sizeof(T) == 4) {
+            const float vf = (float)v;
+            if (fn == 5) {
+                const f2 C2[2] = {splat((float)c), splat((float)c)};
+                const float kap = (2.0f - (float)c) * 1.57079637050628662109375f;
+                const f2 k2[2] = {splat(kap), splat(kap)}, xs[2] = {splat(vf), splat(vf)};
+                const f2 ix[2] = {splat(fm::rcp(vf)), splat(fm::rcp(vf))};
+                f2 o[2];
+                sin_c_atan2x2<true>(K, C2, k2, xs, ix, o);
+                a = (T)o[0].x;
+            } else if (fn == 6) {
+                bool ok = true;
+                const f2 r = sincos_mid2(K, vf, ok);
+                a = (T)r.x; b = (T)r.y; two = true;
+            } else if (fn == 7) {
+                const f2 r = stage_rot2(K, vf);
+                a = (T)r.x; b = (T)r.y; two = true;
+            } else if (fn == 8) {
+                const f2 r = sincos_kernel2(K, vf);
+                a = (T)r.x; b = (T)r.y; two = true;
+            }
+        }
+        break;
+    }
+    out0[i] = a;
+    if (two && out1 != nullptr) out1[i] = b;
+}
+
 // ---------------------------------------------------------------- launchers ---------
 
 template <typename T>
@@ -1133,6 +1218,11 @@ static hipError_t launch_rollout_fleet_impl(const RolloutArgs<T> &a, hipStream_t
         const size_t per_step = (size_t)a.P * K * sizeof(T);
         chunk = (int)std::min<size_t>((size_t)chunk, std::max<size_t>(1, (kLdsBudget - 16 * 1024) / per_step));
         lds += (size_t)chunk * per_step;
+    }
+    if (lds > 64 * 1024) {      // 256 fp64 classes alone are 58 KiB: beyond the default limit a workgroup opts in (160 KiB per CU)
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_fleet_kernel<T, K, LAYOUT, CS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return e_;
     }
     hipLaunchKernelGGL((rollout_fleet_kernel<T, K, LAYOUT, CS>), dim3(grid), dim3(kBlock), lds, st, a.fleet_tab, a.V,
                        a.vehicle_id, a.n, a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
@@ -1243,6 +1333,24 @@ hipError_t launch_rollout_spiral(const VdynParams &p, int64_t n, int H, const T 
     else
         hipLaunchKernelGGL((rollout_spiral_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral,
                            (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_nonfinite_lanes(int rows, int64_t n, const T *x, int *status, unsigned long long *count, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((nonfinite_lanes_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, n,
+                       x, status, count);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_fastmath_eval(int fn, int64_t n, const T *x, double c, T *out0, T *out1, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((fastmath_eval_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, fn, n, x,
+                       (T)c, out0, out1);
     return hipGetLastError();
 }
 
@@ -1436,6 +1544,8 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
     template hipError_t launch_rollout_spiral<T>(const VdynParams &, int64_t, int, const T *, const T *, double, \
                                                  double, double, double, const double *, T *, T *, int, hipStream_t); \
+    template hipError_t launch_nonfinite_lanes<T>(int, int64_t, const T *, int *, unsigned long long *, hipStream_t); \
+    template hipError_t launch_fastmath_eval<T>(int, int64_t, const T *, double, T *, T *, hipStream_t); \
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
                                                const T *, T *, T *, T *, T *, hipStream_t);          \
     template hipError_t launch_mpc_argmin<T>(const VdynParams &, int, int, int, const T *, const T *, \

@@ -206,6 +206,10 @@ class VehicleModel:
         # out: state12[0:12] state_dot[12:22] outputs[22:40]
         h.call("vdyn_step_f64_host", 1, a[0], a[24], 12, float(self.dt), None, a[40], a[52], a[62])
         o = self._sc_out.copy()
+        if not np.isfinite(o[0:12]).all():      # the reference: inf / nan + NumPy's RuntimeWarning (vehicle_model.py:284-293)
+            import warnings
+            warnings.warn("non-finite value encountered in planar_model_RK4 (division by a zero wheel-plane speed)",
+                          RuntimeWarning, stacklevel=2)
         su = o[0:10]
         return [su, su[8], su[9], su[7], su[0], o[12:22], o[22:40], o[10], o[11]]
 
@@ -662,6 +666,34 @@ class VehicleModel:
             f"vdyn_interpolate_waypoints_{be.suffix}_{be.kind}", E, P, L, _vp(pa), _vp(bi), float(res), int(Wmax),
             _vp(wp), _vp(wc), *be.stream_args())
         return wp, wc
+
+    def nonfinite_lanes(self, x):
+        """``x [rows][N]`` (terminal states, a trajectory slice ...) -> ``(status [N] int32, count)``:
+        status 1 where any row of the lane is inf / NaN -- the batched counterpart of the RuntimeWarning
+        NumPy raises in the reference when a wheel speed is zero (vehicle_model.py:284-293)."""
+        be = _Backend(x)
+        a = be.inp(x)
+        if a.ndim != 2:
+            raise ValueError("x must be [rows][N]")
+        rows, n = int(a.shape[0]), int(a.shape[1])
+        st = be.out(n, int32=True)
+        cnt = C.c_int64(0)
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_nonfinite_lanes_{be.suffix}_{be.kind}", rows, n, _vp(a), _vp(st), C.byref(cnt), *be.stream_args())
+        return st, int(cnt.value)
+
+    def fastmath_eval(self, fn, x, c=0.0):
+        """Device self-test hook (include/vdyn.h, vdyn_fastmath_eval_*): evaluate elementary function
+        ``fn`` of the FAST step on ``x [N]`` -> ``(out0, out1)``."""
+        be = _Backend(x)
+        a = be.inp(x)
+        if a.ndim != 1:
+            raise ValueError("x must be 1-D")
+        o0, o1 = be.out(a.shape[0]), be.out(a.shape[0])
+        self._handle(be.device_index(self.device)).call(
+            f"vdyn_fastmath_eval_{be.suffix}_{be.kind}", int(fn), int(a.shape[0]), _vp(a), float(c), _vp(o0), _vp(o1),
+            *be.stream_args())
+        return o0, o1
 
     def synchronize(self, device=None):
         """Wait for the default stream of `device` (NumPy calls are already synchronous)."""
