@@ -272,7 +272,11 @@ int vdyn_controller_update_f32_host(VdynHandle *h, const VdynCtrlGains *g, int64
  *    torque, target index, crosstrack error; datalog (nullable) [H][45][n] = the 45 columns
  *    the reference writes into Car.DataLog per sub-step (drive.py:145-151, names
  *    plots.py:19-27): t = (phase + step) * dt, state x10, state_dot x10, delta, torque x4,
- *    outputs x18, crosstrack error.                                                           */
+ *    outputs x18, crosstrack error.
+ * The target index and crosstrack error the log rows repeat between controller updates are not part of
+ * cstate: a launch whose `phase` is not a multiple of ctrl_every logs index -1 / error 0 until its first
+ * update (the trajectory itself is unaffected: commands ARE carried).  Chain launches at multiples of
+ * ctrl_every (Car.drive's frames are: 100 = 10 x 10) when the log columns matter.                  */
 int vdyn_closed_loop_f64_dev(VdynHandle *h, const VdynCtrlGains *g, int64_t n, int32_t H, int32_t ctrl_every,
                              int32_t phase, const double *state0, const double *cstate_in, const double *wp,
                              int32_t Wmax, const int32_t *wcount, const int32_t *path_id, int32_t P,

@@ -63,6 +63,23 @@ def parity(got, want, tol, what=""):
     return worst
 
 
+def parity_elementwise(got, want, tol, floor_frac=1e-2, what=""):
+    """The stricter reading of the same bar: every ELEMENT that is at least `floor_frac` of its row's scale
+    is held to `tol` relative to ITSELF (|got - want| <= tol * max(|want|, floor_frac * row scale)); smaller
+    elements -- rows that cross zero -- are held to the absolute floor tol * floor_frac * row scale.
+    With floor_frac = 1e-2 that is 100 times tighter on small entries than `parity`."""
+    g = np.asarray(got, dtype=np.float64)
+    w = np.asarray(want, dtype=np.float64)
+    assert g.shape == w.shape and np.isfinite(w).all() and np.isfinite(g).all(), what
+    if g.size == 0:
+        return 0.0
+    scale = np.maximum(np.abs(w).max(axis=-1, keepdims=True), 1e-30)
+    err = np.abs(g - w) / np.maximum(np.abs(w), floor_frac * scale)
+    worst = float(err.max())
+    assert worst <= tol, f"{what}: element-wise relative error {worst:.3e} > {tol:g} (floor {floor_frac:g} of the row scale)"
+    return worst
+
+
 @pytest.fixture(scope="session")
 def gpu_vm(pkg):
     """VehicleModel factory on cuda:0; skips nothing: -m gpu tests REQUIRE the HIP path."""
