@@ -45,6 +45,10 @@ template <typename T, bool SAFE> struct Math;
 
 template <> struct Math<float, false> {
     static constexpr bool kHasRangeLimit = true;
+    static constexpr bool kTrim = false;               // the fp32 hot path is the packed step (vdyn_packed.hpp)
+    static __device__ __forceinline__ void stage_rot(float, float *, float *) {}
+    static constexpr float kStageLimit = 0.0f;
+    static __device__ __forceinline__ void sincos_steer(float d, float *s, float *c, bool &ok) { sincos(d, s, c, ok); }
     static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
     // sin(C atan(x)), inv_x = 1/x.  CS: the host guarantees 0 <= C <= 2 and B >= 0, so
@@ -74,6 +78,10 @@ template <> struct Math<float, false> {
 
 template <> struct Math<float, true> {
     static constexpr bool kHasRangeLimit = false;
+    static constexpr bool kTrim = false;
+    static __device__ __forceinline__ void stage_rot(float, float *, float *) {}
+    static constexpr float kStageLimit = 0.0f;
+    static __device__ __forceinline__ void sincos_steer(float d, float *s, float *c, bool &ok) { sincos(d, s, c, ok); }
     static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
     template <bool CS>
@@ -109,10 +117,23 @@ template <> struct Math<double, false> {
         *c = ::fma(cy0, cd, -sy0 * sd);
         ok = ok && (::fabs(d) <= fm64::kSincosKernelLimit);
     }
+    // the trimmed fp64 FAST step (kTrim): stages work in the frame of the step's initial yaw
+    static constexpr bool kTrim = true;
+    static __device__ __forceinline__ void stage_rot(double d, double *s, double *c) { fm64::small_sincos(d, s, c); }
+    static constexpr double kStageLimit = fm64::kStageYawLimit64;
+    static __device__ __forceinline__ void sincos_steer(double d, double *s, double *c, bool &ok)
+    {
+        fm64::sincos_kernel(d, s, c);                      // |delta| <= pi/4: no reduction; beyond: SAFE
+        ok = ok && (::fabs(d) <= fm64::kSincosKernelLimit);
+    }
 };
 
 template <> struct Math<double, true> {
     static constexpr bool kHasRangeLimit = false;
+    static constexpr bool kTrim = false;
+    static __device__ __forceinline__ void stage_rot(double, double *, double *) {}
+    static constexpr double kStageLimit = 0.0;
+    static __device__ __forceinline__ void sincos_steer(double d, double *s, double *c, bool &ok) { sincos(d, s, c, ok); }
     static __device__ __forceinline__ double rcp(double x) { return fm64::rcp(x); }
     static __device__ __forceinline__ double rsqrt(double x) { return fm64::rsq(x); }
     template <bool CS>
@@ -131,8 +152,8 @@ __device__ __forceinline__ float abs_t(float a) { return ::fabsf(a); }
 __device__ __forceinline__ double abs_t(double a) { return ::fabs(a); }
 __device__ __forceinline__ float tiny_t(float) { return 1e-30f; }     // sqrt = 1e-15: (B s)^2 below fp32 ulp
 __device__ __forceinline__ double tiny_t(double) { return 1e-280; }   // sqrt = 1e-140
-__device__ __forceinline__ float steer_limit_t(float) { return fm::kSincosMidLimit; }      // the range Math<T, false>::sincos validates
-__device__ __forceinline__ double steer_limit_t(double) { return fm64::kSincosMidLimit; }
+__device__ __forceinline__ float steer_limit_t(float) { return fm::kSincosMidLimit; }      // the range Math<T, false>::sincos_steer validates
+__device__ __forceinline__ double steer_limit_t(double) { return fm64::kSincosKernelLimit; }
 __device__ __forceinline__ float sqrt_t(float a) { return ::sqrtf(a); }
 __device__ __forceinline__ double sqrt_t(double a) { return ::sqrt(a); }
 
@@ -143,6 +164,7 @@ struct StepInv {
     T Fz[4];         // normal loads from the PREVIOUS step's accelerations (:255-258, quirk Q3)
     T muFz[4];       // mu_max_i * Fz_i  (mu_max replaces Pacejka D, :232-235, quirk Q1)
     T tq[4];         // wheel torques (:226)
+    T phiB[4];       // (C - 1) pi/2: phase of the x > 1 branch of sin(C atan x) in its cosine form (trimmed step)
 };
 
 // K2 = true: the drive.py:142-143 pattern -- delta[1] == delta[0], rear angles exactly
@@ -164,7 +186,7 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
         c.cd[0] = cd0;
         if (PRE == 1) ok = ok && (abs_t(delta[0]) <= steer_limit_t(T(0)));
     } else {
-        M::sincos(delta[0], &c.sd[0], &c.cd[0], ok);
+        M::sincos_steer(delta[0], &c.sd[0], &c.cd[0], ok);
     }
     if (K2) {
         c.sd[1] = c.sd[0];
@@ -172,10 +194,12 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
         c.sd[2] = c.sd[3] = T(0);
         c.cd[2] = c.cd[3] = T(1);
     } else {
-        M::sincos(delta[1], &c.sd[1], &c.cd[1], ok);
-        M::sincos(delta[2], &c.sd[2], &c.cd[2], ok);
-        M::sincos(delta[3], &c.sd[3], &c.cd[3], ok);
+        M::sincos_steer(delta[1], &c.sd[1], &c.cd[1], ok);
+        M::sincos_steer(delta[2], &c.sd[2], &c.cd[2], ok);
+        M::sincos_steer(delta[3], &c.sd[3], &c.cd[3], ok);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.phiB[i] = (P.C[i] - T(1)) * T(1.5707963267948966192313);
     // :255-258
     c.Fz[0] = P.Fz0F - P.DfzxL * ax_prev - P.DfzyF * ay_prev;
     c.Fz[1] = P.Fz0F - P.DfzxR * ax_prev + P.DfzyF * ay_prev;
@@ -193,7 +217,7 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
 //   :274-281 rotation, :284-293 slips (quirk Q4: signed vx for s_x, |vx| for s_y),
 //   :296-299 combined slip, :303-348 Pacejka + split, :351-373 forces.
 template <typename T, bool STEERED, bool SAFE, bool CS>
-__device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
+__device__ __forceinline__ void tire_force(T B, T invB, T C, T phiB, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
                                            T &fx, T &fy, T &fxt, T &fyt, T &s_out)
 {
     using M = Math<T, SAFE>;
@@ -204,6 +228,28 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, T rw, T vxc, T vyc,
     } else {
         vx = vxc;
         vy = vyc;
+    }
+    if (M::kTrim && CS) {
+        // trimmed form (as vdyn_packed.hpp): slips pre-multiplied by B >= 0, so x = B s comes out of the
+        // rsq that normalises the slip, 1/x is that rsq, and B cancels in s_x mu / s; sin in its cosine form
+        const T rvxB = M::rcp(vx) * B;
+        const T sxb = fma_t(rw, w, -vx) * rvxB;
+        const T syb = -vy * abs_t(rvxB);
+        const T x2 = sxb * sxb + syb * syb;
+        const T x2c = x2 > tiny_t(T(0)) ? x2 : tiny_t(T(0));      // quirk Q5, see below
+        const T rx = M::rsqrt(x2c);
+        const T gf = fm64::sin_c_atan_cs(C, phiB, x2c * rx, rx) * rx * muFz;
+        fxt = sxb * gf;
+        fyt = syb * gf;
+        if (STEERED) {
+            fx = fxt * cd - fyt * sd;
+            fy = fxt * sd + fyt * cd;
+        } else {
+            fx = fxt;
+            fy = fyt;
+        }
+        s_out = x2 * rx * invB;
+        return;
     }
     const T rvx = M::rcp(vx);
     // rw*w/vx - 1 == (rw*w - vx)/vx; the fused form rounds the small
@@ -253,22 +299,33 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     const T vFy = V + P.a * wz, vRy = V - P.b * wz;
 
     T fx[4], fy[4], fxt[4], fyt[4], sl[4];
-    tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0], c.muFz[0],
-                              fx[0], fy[0], fxt[0], fyt[0], sl[0]);
-    tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1], c.muFz[1],
-                              fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-    tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2], c.muFz[2],
-                             fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-    tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3], c.muFz[3],
-                             fx[3], fy[3], fxt[3], fyt[3], sl[3]);
+    tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], c.phiB[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0],
+                              c.muFz[0], fx[0], fy[0], fxt[0], fyt[0], sl[0]);
+    tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], c.phiB[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1],
+                              c.muFz[1], fx[1], fy[1], fxt[1], fyt[1], sl[1]);
+    tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], c.phiB[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
+                             c.muFz[2], fx[2], fy[2], fxt[2], fyt[2], sl[2]);
+    tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], c.phiB[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
+                             c.muFz[3], fx[3], fy[3], fxt[3], fyt[3], sl[3]);
 
     // :376-385
-    const T Udot = P.inv_m * (fx[0] + fx[1] + fx[2] + fx[3]) + V * wz;
-    const T Vdot = P.inv_m * (fy[0] + fy[1] + fy[2] + fy[3]) - U * wz;
+    T Udot, Vdot;
+    if (Math<T, SAFE>::kTrim) {
+        // :413-414 first: axc = U_dot - V wz and ayc = V_dot + U wz ARE the force sums over m
+        axc = P.inv_m * (fx[0] + fx[1] + fx[2] + fx[3]);
+        ayc = P.inv_m * (fy[0] + fy[1] + fy[2] + fy[3]);
+        Udot = fma_t(V, wz, axc);
+        Vdot = fma_t(-U, wz, ayc);
+        const T aI = P.a * P.inv_Izz, bI = P.b * P.inv_Izz, hI = P.half_T * P.inv_Izz;     // loop-invariant
+        k[2] = aI * (fy[0] + fy[1]) - bI * (fy[2] + fy[3]) + hI * (fx[1] - fx[0] + fx[3] - fx[2]);
+    } else {
+        Udot = P.inv_m * (fx[0] + fx[1] + fx[2] + fx[3]) + V * wz;
+        Vdot = P.inv_m * (fy[0] + fy[1] + fy[2] + fy[3]) - U * wz;
+        k[2] = P.inv_Izz * (P.a * (fy[0] + fy[1]) - P.b * (fy[2] + fy[3])
+                            + P.half_T * (fx[1] - fx[0] + fx[3] - fx[2]));
+    }
     k[0] = Udot;
     k[1] = Vdot;
-    k[2] = P.inv_Izz * (P.a * (fy[0] + fy[1]) - P.b * (fy[2] + fy[3])
-                        + P.half_T * (fx[1] - fx[0] + fx[3] - fx[2]));
     // quirk Q2: front wheels see the tire-frame force, rear wheels the chassis-frame one
     k[3] = (c.tq[0] - P.rw * fxt[0]) * P.inv_Jw;
     k[4] = (c.tq[1] - P.rw * fxt[1]) * P.inv_Jw;
@@ -277,8 +334,10 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     k[7] = wz;
     k[8] = U * cy - V * sy;
     k[9] = U * sy + V * cy;
-    axc = Udot - V * wz;  // :413
-    ayc = Vdot + U * wz;  // :414
+    if (!Math<T, SAFE>::kTrim) {
+        axc = Udot - V * wz;  // :413
+        ayc = Vdot + U * wz;  // :414
+    }
     if (DIAG) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -314,13 +373,19 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
     T sy0, cy0, sy, cy;
     M::sincos(s[7], &sy0, &cy0, ok);
 
-    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, s, sy0, cy0, k, a1, a2, &o);       // K1 (:429)
+    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, s, M::kTrim ? T(0) : sy0, M::kTrim ? T(1) : cy0, k, a1, a2, &o);       // K1 (:429)
     asx = a1; asy = a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = k[i]; st[i] = fma_t(hh, k[i], s[i]); }
     if (DIAG) osum = o;
 
-    M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
+    // Trimmed FAST step (Math::kTrim): x, y and yaw feed no derivative, so stages 2-4 only need the rotation by
+    // their yaw INCREMENT d = yaw_stage - yaw (a short Taylor form, |d| <= 1/32), k[8], k[9] are accumulated in
+    // the frame of the initial yaw and the 1-2-2-1 sum is rotated into the global frame once
+    // (R(yaw) sum_j w_j R(d_j) u_j == sum_j w_j R(yaw + d_j) u_j).
+    T d2 = T(0), d3 = T(0), d4 = T(0);
+    if (M::kTrim) { d2 = hh * k[7]; M::stage_rot(d2, &sy, &cy); }
+    else M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
     planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K2 (:431)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
@@ -330,7 +395,8 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
         for (int i = 0; i < 18; ++i) osum.v[i] += T(2) * o.v[i];
     }
 
-    M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
+    if (M::kTrim) { d3 = hh * k[7]; M::stage_rot(d3, &sy, &cy); }
+    else M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
     planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K3 (:433)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
@@ -340,15 +406,25 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
         for (int i = 0; i < 18; ++i) osum.v[i] += T(2) * o.v[i];
     }
 
-    M::stage_sincos(sy0, cy0, st[7], h * k[7], &sy, &cy, ok);
+    if (M::kTrim) { d4 = h * k[7]; M::stage_rot(d4, &sy, &cy); }
+    else M::stage_sincos(sy0, cy0, st[7], h * k[7], &sy, &cy, ok);
     planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K4 (:435)
     asx += a1; asy += a2;
+    if (M::kTrim) {
+        T m = abs_t(d2) > abs_t(d3) ? abs_t(d2) : abs_t(d3);
+        m = m > abs_t(d4) ? m : abs_t(d4);
+        ok = ok && (m <= M::kStageLimit);
+    }
     const T h6 = h * T(1.0 / 6.0), sixth = T(1.0 / 6.0);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        acc[i] += k[i];
-        sn[i] = fma_t(h6, acc[i], s[i]);                                     // :438
+    for (int i = 0; i < 10; ++i) acc[i] += k[i];
+    if (M::kTrim) {                                                          // into the global frame
+        const T gx = acc[8] * cy0 - acc[9] * sy0, gy = acc[8] * sy0 + acc[9] * cy0;
+        acc[8] = gx;
+        acc[9] = gy;
     }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) sn[i] = fma_t(h6, acc[i], s[i]);            // :438
     axn = asx * sixth;                                                       // :442
     ayn = asy * sixth;                                                       // :443
     if (DIAG) {

@@ -553,7 +553,7 @@ struct StepEngine {
     __device__ __forceinline__ void steer_sincos(T d, T &sd, T &cd) const
     {
         bool ok = true;
-        Math<T, false>::sincos(d, &sd, &cd, ok);
+        Math<T, false>::sincos_steer(d, &sd, &cd, ok);
     }
     template <bool K2, bool CS, int PRE = 0>
     __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
