@@ -622,10 +622,11 @@ struct StepEngine<float> {
         const bool ok = rk4_step2<K2, CS, false, PRE>(P, Q, K, S, X.axy, delta, tq, mu, h, A, axy_n, nullptr, nullptr,
                                                       nullptr, nullptr, f2{sd0, cd0});
         const f2 h6 = splat(h * (1.0f / 6.0f));
-        // The state is advanced IN PLACE on the normal path: the old state's last use is the very fma that
-        // produces the new one, so no register copy is needed per step.  Only when some lane of the wave
-        // left the FAST range (wave-uniform branch, normally not taken) is the old state kept alive for
-        // that lane's SAFE redo.
+        // The normal path finishes with s += h/6 acc after the wave-uniform range test; only when some lane
+        // left the FAST range (normally never) is the old state needed again, for that lane's SAFE redo.
+        // (The allocator still keeps the post-step state in a second set of registers and copies it back at
+        // the loop latch -- six v_mov_b64 per step; tying the fma's destination to the state's registers with
+        // inline asm, on both paths, did not change that, nor did a 512-VGPR budget.)
         if (__builtin_expect(__any(!ok) != 0, 0)) {
             if (!ok) {
                 float s[10], sn[10], axn, ayn;
