@@ -5,8 +5,10 @@
 // (U, V), (x, y), (wz, yaw), (sin, cos), (axc, ayc).  Rotations and cross products are one or two
 // VOP3P instructions each (pk_cross / pk_hi_conj / pk_rot90 with the per-half sign bits), the
 // atan range split is the compare-free clamp indicator of vdyn_packed.hpp, and the integrator
-// state is three pairs + the lane's wheel speed.  457 -> ~320 VALU instructions per RK4 step, all
-// of it on a wave's critical path (these kernels run where the chip is mostly empty).
+// state is three pairs + the lane's wheel speed.  457 -> 348 (round 1) -> ~285 VALU instructions per RK4 step with
+// the trims of the lane kernel (vdyn_packed.hpp: slips pre-multiplied by B, degree-7 atan, sin(C theta) in its cosine
+// form, force sums instead of accelerations, stage yaw increments as small rotations in the initial-yaw frame, mod-pi
+// sincos of yaw), all of it on a wave's critical path (these kernels run where the chip is mostly empty).
 //
 // Semantics: those of rk4_step_quad<float, false, true> (vdyn_quad.hpp).  Only the CS = true FAST
 // step is specialised; CS = false and the SAFE redo use the scalar code unchanged.
@@ -39,9 +41,13 @@ struct QuadEngine {
 template <>
 struct QuadEngine<float> {
     f2 sck[3];        // (sin, cos) kernel coefficients, as in PkConsts
+    f2 scp[4];        // (sin, cos) on |r| <= pi/2 in one chain (PkConsts::scp)
+    f2 rot_a, rot_b, rot_c;
     f2 lv;            // (side T/2, lever): corner velocity = (U, V) + lv wz   (:261-271)
     f2 inv_m2;
-    float neg_rw_Jw, inv_Jw, moment_x;   // -rw / Jw; 1 / Jw; side T/2 (yaw moment arm of fx, :378)
+    float neg_rw_Jw, inv_Jw;             // -rw / Jw; 1 / Jw
+    float mom_x, mom_y;                  // side T/2 / Izz, lever / Izz: yaw-moment arms of (fx, fy) (:378)
+    float kappa;                         // (2 - C) pi/2: phase of the x > 1 branch (sin_c_atan2x2)
 
     __device__ __forceinline__ void init(const DevParams<float> &P, const WheelLane<float> &L)
     {
@@ -52,13 +58,26 @@ struct QuadEngine<float> {
             sck[i] = f2{sks[i], cks[i]};
             asm volatile("" : "+v"(sck[i]));
         }
-        float hT = P.half_T, im = P.inv_m, iJ = P.inv_Jw, r_w = P.rw;
-        asm("" : "+v"(hT), "+v"(im), "+v"(iJ), "+v"(r_w));     // see PkParams::init on why
-        moment_x = L.side * hT;
-        lv = f2{moment_x, L.lever};
+        const float sn[4] = {2.607052693e-06f, -1.981028618e-04f, 8.333077654e-03f, -1.666665971e-01f};
+        const float cc[4] = {2.312937249e-05f, -1.385257230e-03f, 4.166342318e-02f, -4.999989867e-01f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            scp[i] = f2{sn[i], cc[i]};
+            asm volatile("" : "+v"(scp[i]));
+        }
+        rot_a = f2{-1.0f / 6.0f, 1.0f / 24.0f};
+        rot_b = f2{1.0f, -0.5f};
+        rot_c = f2{0.0f, 1.0f};
+        asm volatile("" : "+v"(rot_a), "+v"(rot_b), "+v"(rot_c));
+        float hT = P.half_T, im = P.inv_m, iJ = P.inv_Jw, r_w = P.rw, iIz = P.inv_Izz;
+        asm("" : "+v"(hT), "+v"(im), "+v"(iJ), "+v"(r_w), "+v"(iIz));     // see PkParams::init on why
+        lv = f2{L.side * hT, L.lever};
+        mom_x = L.side * hT * iIz;
+        mom_y = L.lever * iIz;
         inv_m2 = f2{im, im};
         inv_Jw = iJ;
         neg_rw_Jw = -r_w * iJ;
+        kappa = (2.0f - L.C) * 1.57079637050628662109375f;
     }
 
     __device__ __forceinline__ f2 sincos_k(float r) const
@@ -69,19 +88,27 @@ struct QuadEngine<float> {
         p = fma2(p, u2, sck[2]);
         return fma2(f2{r, u} * u2, p, f2{r, ::fmaf(-0.5f, u, 1.0f)});
     }
-    __device__ __forceinline__ f2 sincos_full(float x, bool &ok) const      // fm::sincos_mid on a pair
+    // (sin x, cos x) of the unwrapped yaw: x = k pi + r, one packed chain (sincos_mid2 of vdyn_packed.hpp)
+    __device__ __forceinline__ f2 sincos_full(float x, bool &ok) const
     {
-        const float k = __builtin_rintf(x * 0.636619772367581343076f);
-        float r = ::fmaf(-k, 1.57079637050628662109375f, x);
-        r = ::fmaf(-k, -4.37113900018624283e-08f, r);
-        r = ::fmaf(-k, -1.7151245100059e-15f, r);
-        const f2 sc = sincos_k(r);
-        const int q = (int)k;
-        const bool swap = (q & 1) != 0;
-        const float s0 = swap ? sc.y : sc.x, c0 = swap ? sc.x : sc.y;
-        const unsigned fs = ((unsigned)(q & 2)) << 30, fc = ((unsigned)((q + 1) & 2)) << 30;
+        const float k = __builtin_rintf(x * 0.318309886183790671538f);
+        float r = ::fmaf(-k, 3.1415927410125732421875f, x);
+        r = ::fmaf(-k, -8.74227800037248566e-08f, r);
+        const float u = r * r;
+        const f2 u2 = f2{u, u};
+        f2 p = fma2(scp[0], u2, scp[1]);
+        p = fma2(p, u2, scp[2]);
+        p = fma2(p, u2, scp[3]);
+        const f2 sc = fma2(f2{r * u, u}, p, f2{r, 9.999999404e-01f});
+        const unsigned flip = ((unsigned)(int)k) << 31;
         ok = ok && (::fabsf(x) <= fm::kSincosMidLimit);
-        return f2{__uint_as_float(__float_as_uint(s0) ^ fs), __uint_as_float(__float_as_uint(c0) ^ fc)};
+        return f2{__uint_as_float(__float_as_uint(sc.x) ^ flip), __uint_as_float(__float_as_uint(sc.y) ^ flip)};
+    }
+    __device__ __forceinline__ f2 stage_rot(float d) const                 // stage_rot2 of vdyn_packed.hpp
+    {
+        const float u = d * d;
+        const f2 a = fma2(f2{u, u}, rot_a, rot_b);
+        return fma2(f2{d, u}, a, rot_c);
     }
 
     struct Lane3 {
@@ -90,43 +117,52 @@ struct QuadEngine<float> {
     };
 
     // One derivative evaluation (vehicle_model.py:220-425) for this lane's wheel + the replicated chassis.
+    // sc = (sin, cos) of the stage's yaw INCREMENT (FIRST: zero): k.xy lives in the frame of the initial yaw.
+    // sums = (sum Fx, sum Fy): :413-414's axc, ayc are these over m, scaled once by the caller.
+    template <bool FIRST>
     __device__ __forceinline__ void deriv(const DevParams<float> &P, const WheelLane<float> &L, f2 dsc, float muFz,
-                                          float tqJ, const Lane3 &s, f2 sc, Lane3 &k, f2 &acc_c) const
+                                          float tqJ, const Lane3 &s, f2 sc, Lane3 &k, f2 &sums) const
     {
         const f2 wz2 = f2{s.wy.x, s.wy.x};
         const f2 vv = fma2(lv, wz2, s.uv);                                // corner velocity, chassis frame
         const f2 tv = fma2(vv, f2{dsc.y, dsc.y}, pk_cross(vv, dsc));      // :274-281 (vx, vy), tire frame
-        const float rvx = fm::rcp(tv.x);
-        const float sx = ::fmaf(P.rw, s.w, -tv.x) * rvx;                  // :284-287
-        const float sy = -tv.y * ::fabsf(rvx);                            // :290-293 (quirk Q4)
-        const float s2 = ::fmaf(sx, sx, ::fmaf(sy, sy, 1e-30f));          // :296-299, quirk Q5 (see tire_force2x2)
-        const float rs = fm::rsq(s2);
-        const float xs = L.B * (s2 * rs), ix = rs * L.invB;
-        // sin(C atan(x)), x >= 0: reduced argument min(x, 1/x), atan = p + [x > 1] (pi/2 - 2 p)
-        const float t = ::fminf(xs, ix);
+        const float rvxB = fm::rcp(tv.x) * L.B;                           // B / vx (B >= 0: CS)
+        const float sx = ::fmaf(P.rw, s.w, -tv.x) * rvxB;                 // B s_x   (:284-287)
+        const float sy = -tv.y * ::fabsf(rvxB);                           // B s_y   (:290-293, quirk Q4)
+        const float x2 = ::fmaf(sx, sx, ::fmaf(sy, sy, 1e-30f));          // (B s)^2 (:296-299), quirk Q5 (see tire_force2x2)
+        const float rx = fm::rsq(x2);                                     // 1 / x
+        const float xs = x2 * rx;                                         // x = B s
+        // sin(C atan(x)), x >= 0, in its cosine form: cos(C p - phi), p = atan(min(x, 1/x)), phi = pi/2 - [x > 1] kappa
+        const float t = ::fminf(xs, rx);
         const float ind = __builtin_amdgcn_fmed3f(::fmaf(xs, 0x1p100f, -0x1p100f), 0.0f, 1.0f);
         const float u = t * t;
-        float p = 2.872858429e-03f;
-        p = ::fmaf(p, u, -1.616817340e-02f);
-        p = ::fmaf(p, u, 4.286647215e-02f);
-        p = ::fmaf(p, u, -7.520283014e-02f);
-        p = ::fmaf(p, u, 1.064901948e-01f);
-        p = ::fmaf(p, u, -1.420586258e-01f);
-        p = ::fmaf(p, u, 1.999291778e-01f);
-        p = ::fmaf(p, u, -3.333308995e-01f);
-        p = ::fmaf(p * u, t, t);
-        const float th = ::fmaf(ind, ::fmaf(-2.0f, p, 1.57079637050628662109375f), p);
-        const float g = fm::sin_0_pi(L.C * th) * rs * muFz;               // mu / s times Fz (quirk Q1 in muFz)
+        float p = -4.729942884e-03f;
+        p = ::fmaf(p, u, 2.439327165e-02f);
+        p = ::fmaf(p, u, -5.969851837e-02f);
+        p = ::fmaf(p, u, 9.930104017e-02f);
+        p = ::fmaf(p, u, -1.402552277e-01f);
+        p = ::fmaf(p, u, 1.997082233e-01f);
+        p = ::fmaf(p, u, -3.333206475e-01f);
+        p = ::fmaf(p, u, 9.999998808e-01f);
+        p = p * t;
+        const float z = ::fmaf(L.C, p, -::fmaf(ind, -kappa, 1.57079637050628662109375f));
+        const float w = z * z;
+        float q = ::fmaf(2.312937249e-05f, w, -1.385257230e-03f);
+        q = ::fmaf(q, w, 4.166342318e-02f);
+        q = ::fmaf(q, w, -4.999989867e-01f);
+        q = ::fmaf(q, w, 9.999999404e-01f);
+        const float g = q * rx * muFz;                                    // mu / s times Fz over B (B cancels with the scaled slips)
         const f2 ft = f2{sx, sy} * f2{g, g};                              // :351-360 (fxt, fyt)
         const f2 fc = fma2(ft, f2{dsc.y, dsc.y}, pk_rot90(ft, dsc));      // :363-373 (fx, fy), chassis frame
         const float Sfx = quad_sum(fc.x), Sfy = quad_sum(fc.y);
-        const float Mz = quad_sum(::fmaf(L.lever, fc.y, moment_x * fc.x));   // :378
+        const float wzdot = quad_sum(::fmaf(mom_y, fc.y, mom_x * fc.x));  // :378, arms pre-divided by Izz
+        sums = f2{Sfx, Sfy};
         const f2 cross = pk_cross(s.uv, s.wy);                            // (V wz, -U wz)
-        k.uv = fma2(inv_m2, f2{Sfx, Sfy}, cross);                         // :376-377
-        acc_c = k.uv - cross;                                             // :413-414
-        k.wy = f2{P.inv_Izz * Mz, s.wy.x};
+        k.uv = fma2(inv_m2, sums, cross);                                 // :376-377
+        k.wy = f2{wzdot, s.wy.x};
         k.w = ::fmaf(neg_rw_Jw, L.front ? ft.x : fc.x, tqJ);              // :379-382, quirk Q2
-        k.xy = fma2(f2{s.uv.x, s.uv.x}, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));   // :384-385
+        if (FIRST) k.xy = s.uv;
+        else k.xy = fma2(f2{s.uv.x, s.uv.x}, f2{sc.y, sc.x}, pk_hi_conj(s.uv, sc));   // :384-385, initial-yaw frame
     }
 
     // FAST RK4 step (vehicle_model.py:427-445); false when the lane left the validated range.
@@ -141,47 +177,49 @@ struct QuadEngine<float> {
         const f2 hh2 = f2{hh, hh}, h2 = f2{h, h}, two = f2{2.0f, 2.0f};
         const f2 sc0 = sincos_full(s.wy.y, ok);
         Lane3 k, acc, st;
-        f2 a, as2, sc;
-#define VDYN_L3_EACH(OP) OP(uv) OP(wy) OP(xy)
-#define VDYN_ROT(d)                                                              \
-    {                                                                            \
-        const float d_ = (d);                                                    \
-        const f2 dd = sincos_k(d_);                                              \
-        ok = ok && (::fabsf(d_) <= fm::kSincosKernelLimit);                      \
-        sc = fma2(sc0, f2{dd.y, dd.y}, pk_cross(sc0, dd));                       \
-    }
-        deriv(P, L, dsc, muFz, tqJ, s, sc0, k, a);                        // K1
+        f2 a, as2;
+        float d2, d3, d4;
+#define VDYN_L2_EACH(OP) OP(uv) OP(wy)
+        deriv<true>(P, L, dsc, muFz, tqJ, s, sc0, k, a);                  // K1
         as2 = a;
 #define VDYN_L3_1(f) acc.f = k.f; st.f = fma2(hh2, k.f, s.f);
-        VDYN_L3_EACH(VDYN_L3_1)
+        VDYN_L2_EACH(VDYN_L3_1)
+        acc.xy = k.xy;
         acc.w = k.w; st.w = ::fmaf(hh, k.w, s.w);
-        VDYN_ROT(hh * k.wy.y)
-        deriv(P, L, dsc, muFz, tqJ, st, sc, k, a);                        // K2
+        d2 = hh * k.wy.y;
+        deriv<false>(P, L, dsc, muFz, tqJ, st, stage_rot(d2), k, a);      // K2
         as2 = fma2(two, a, as2);
 #define VDYN_L3_2(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(hh2, k.f, s.f);
-        VDYN_L3_EACH(VDYN_L3_2)
+        VDYN_L2_EACH(VDYN_L3_2)
+        acc.xy = fma2(two, k.xy, acc.xy);
         acc.w = ::fmaf(2.0f, k.w, acc.w); st.w = ::fmaf(hh, k.w, s.w);
-        VDYN_ROT(hh * k.wy.y)
-        deriv(P, L, dsc, muFz, tqJ, st, sc, k, a);                        // K3
+        d3 = hh * k.wy.y;
+        deriv<false>(P, L, dsc, muFz, tqJ, st, stage_rot(d3), k, a);      // K3
         as2 = fma2(two, a, as2);
 #define VDYN_L3_3(f) acc.f = fma2(two, k.f, acc.f); st.f = fma2(h2, k.f, s.f);
-        VDYN_L3_EACH(VDYN_L3_3)
+        VDYN_L2_EACH(VDYN_L3_3)
+        acc.xy = fma2(two, k.xy, acc.xy);
         acc.w = ::fmaf(2.0f, k.w, acc.w); st.w = ::fmaf(h, k.w, s.w);
-        VDYN_ROT(h * k.wy.y)
-        deriv(P, L, dsc, muFz, tqJ, st, sc, k, a);                        // K4
+        d4 = h * k.wy.y;
+        deriv<false>(P, L, dsc, muFz, tqJ, st, stage_rot(d4), k, a);      // K4
         as2 = as2 + a;
+        ok = ok && (::fmaxf(::fmaxf(::fabsf(d2), ::fabsf(d3)), ::fabsf(d4)) <= kStageYawLimit);
         const float sixth = 1.0f / 6.0f, h6 = h * sixth;
         const f2 h62 = f2{h6, h6};
 #define VDYN_L3_4(f) sn.f = fma2(h62, acc.f + k.f, s.f);
-        VDYN_L3_EACH(VDYN_L3_4)
+        VDYN_L2_EACH(VDYN_L3_4)
+        {
+            const f2 b = acc.xy + k.xy;                                    // initial-yaw frame -> global frame
+            const f2 g = fma2(f2{b.x, b.x}, f2{sc0.y, sc0.x}, pk_hi_conj(b, sc0));
+            sn.xy = fma2(h62, g, s.xy);
+        }
         sn.w = ::fmaf(h6, acc.w + k.w, s.w);
 #undef VDYN_L3_1
 #undef VDYN_L3_2
 #undef VDYN_L3_3
 #undef VDYN_L3_4
-#undef VDYN_ROT
-#undef VDYN_L3_EACH
-        axy_n = as2 * f2{sixth, sixth};
+#undef VDYN_L2_EACH
+        axy_n = as2 * (inv_m2 * f2{sixth, sixth});
         return ok;
     }
 
