@@ -106,7 +106,9 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
     return (size_t)P * (rollout_table_pre<K, LAYOUT, DIAG>() ? 4 : K) * sizeof(T);
 }
 
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS>
+// TRAJ: the launch writes trajectory rows.  A separate instance, because the test "is this a trajectory step" is
+// a (taken) branch per step on the normal path otherwise, and a lone wave pays tens of cycles for each.
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
@@ -175,7 +177,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             }
             c = cn;
 
-            if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+            if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;   // written once: streaming stores
 #pragma unroll
                 for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), row + (int64_t)i * n);
@@ -1201,9 +1203,14 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
         chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
         lds = (size_t)chunk * per_step;
     }
-    hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
-                       a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
-                       a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
+    if (a.traj != nullptr || DIAG)
+        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+                           a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                           a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
+    else
+        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+                           a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                           a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
     return hipGetLastError();
 }
 

@@ -622,11 +622,12 @@ struct StepEngine<float> {
         const bool ok = rk4_step2<K2, CS, false, PRE>(P, Q, K, S, X.axy, delta, tq, mu, h, A, axy_n, nullptr, nullptr,
                                                       nullptr, nullptr, f2{sd0, cd0});
         const f2 h6 = splat(h * (1.0f / 6.0f));
-        // The normal path finishes with s += h/6 acc after the wave-uniform range test; only when some lane
-        // left the FAST range (normally never) is the old state needed again, for that lane's SAFE redo.
-        // (The allocator still keeps the post-step state in a second set of registers and copies it back at
-        // the loop latch -- six v_mov_b64 per step; tying the fma's destination to the state's registers with
-        // inline asm, on both paths, did not change that, nor did a 512-VGPR budget.)
+        // s += h/6 acc (:438) unconditionally, then -- behind one wave-uniform, normally-not-taken branch that the
+        // normal path falls through -- the SAFE redo overwrites the lanes that left the FAST range.  (Committing only
+        // after the test, with the update in an else-branch, put a second TAKEN branch on the normal path: a lone wave
+        // pays tens of cycles for each.  The allocator copies the packed state once per step either way.)
+        f2 uv = fma2(h6, A.uv, S.uv), wy = fma2(h6, A.wy, S.wy), wf = fma2(h6, A.wf, S.wf), wr = fma2(h6, A.wr, S.wr),
+           xy = fma2(h6, A.xy, S.xy);
         if (__builtin_expect(__any(!ok) != 0, 0)) {
             if (!ok) {
                 float s[10], sn[10], axn, ayn;
@@ -635,22 +636,13 @@ struct StepEngine<float> {
                 float dl[4] = {delta[0], delta[1], delta[2], delta[3]};
                 if (PRE == 2) dl[0] = dl[1] = ::atanf(delta[0]);        // delta[0] is tan(delta)
                 rk4_step<float, K2, false, true, CS>(P, s, X.axy.x, X.axy.y, dl, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
-#pragma unroll
-                for (int i = 0; i < 10; ++i) X.set(i, sn[i]);
-                X.axy = f2{axn, ayn};
-            } else {
-                X.uv = fma2(h6, A.uv, S.uv); X.wy = fma2(h6, A.wy, S.wy); X.wf = fma2(h6, A.wf, S.wf);
-                X.wr = fma2(h6, A.wr, S.wr); X.xy = fma2(h6, A.xy, S.xy);
-                X.axy = axy_n;
+                uv = f2{sn[0], sn[1]}; wy = f2{sn[2], sn[7]}; wf = f2{sn[3], sn[4]}; wr = f2{sn[5], sn[6]};
+                xy = f2{sn[8], sn[9]};
+                axy_n = f2{axn, ayn};
             }
-        } else {
-            X.uv = fma2(h6, A.uv, X.uv);
-            X.wy = fma2(h6, A.wy, X.wy);
-            X.wf = fma2(h6, A.wf, X.wf);
-            X.wr = fma2(h6, A.wr, X.wr);
-            X.xy = fma2(h6, A.xy, X.xy);
-            X.axy = axy_n;
         }
+        X.uv = uv; X.wy = wy; X.wf = wf; X.wr = wr; X.xy = xy;
+        X.axy = axy_n;
     }
     // the same step on the [10] + 2 scalar form (kernels that read single states between steps)
     template <bool K2, bool CS, int PRE = 0>

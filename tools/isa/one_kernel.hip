@@ -6,7 +6,7 @@
 #define VDYN_ONLY_F64
 #include "vdyn_kernels.hip"
 #ifndef ONE_KERNEL
-#define ONE_KERNEL rollout_kernel<float, 2, 1, false, true>
+#define ONE_KERNEL rollout_kernel<float, 2, 1, false, true, false>
 #endif
 namespace vdyn {
 template __global__ void ONE_KERNEL(DevParams<float>, int64_t, int, const float *, const float *, const int *, int, int,
