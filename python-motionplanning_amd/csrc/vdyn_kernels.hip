@@ -210,7 +210,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
 // the wheelbase: the kinematic-bicycle steering angle of that curvature.
 // No control bytes come from memory at all: 12 B per ROLLOUT instead of 8 B per step, and
 // (sin delta, cos delta) are exact from the tangent -- cos = rsq(1 + tan^2) -- with no arctangent.
-template <typename T, bool CS>
+template <typename T, bool CS, bool TRAJ>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0, const T *__restrict__ spiral,
                       T wheelbase, T tan_max, T torque, T h, T *__restrict__ terminal, T *__restrict__ traj,
@@ -244,7 +244,7 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
         const T sd = q * cd;
         const T delta[4] = {q, q, T(0), T(0)};                     // PRE = 2: the tangent stands in for the angle
         eng.template advance_state<true, CS, 2>(P, X, delta, tq, P.mu, h, sd, cd);
-        if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+        if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
             T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
 #pragma unroll
             for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), row + (int64_t)i * n);
@@ -659,7 +659,8 @@ size_t waypoint_aux_len(int P, int Wmax, bool ldsimg)
 //   DATALOG: datalog [H][45][n] = the 45 columns Car.DataLog receives per sub-step
 //            (drive.py:145-151; names in plots.py:19-27): t, state x10, state_dot x10, delta,
 //            torque x4, outputs x18, crosstrack error.
-template <typename T, bool CS, bool WPLDS, bool DATALOG>
+//   LOG: the launch writes the 16-row log (an instance of its own: see rollout_kernel's TRAJ)
+template <typename T, bool CS, bool WPLDS, bool DATALOG, bool LOG>
 __global__ void __launch_bounds__(kBlock)
 closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_every, int phase,
                    const T *__restrict__ state0, const T *__restrict__ cstate0, const T *__restrict__ wp,
@@ -760,7 +761,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
             VDYN_NT(44, c.cte);                                                   // :151
 #undef VDYN_NT
         }
-        if (log != nullptr && active) {
+        if (LOG && log != nullptr && active) {
             T *row = log + (int64_t)t * 16 * n + r;
 #pragma unroll
             for (int i = 0; i < 12; ++i) row[(int64_t)i * n] = X.get(i);
@@ -1334,12 +1335,15 @@ hipError_t launch_rollout_spiral(const VdynParams &p, int64_t n, int H, const T 
     if (n <= 0) return hipSuccess;
     const DevParams<T> P = make_dev_params<T>(p, mu4);
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-    if (shape_factors_small(p))
-        hipLaunchKernelGGL((rollout_spiral_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral,
-                           (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1);
-    else
-        hipLaunchKernelGGL((rollout_spiral_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral,
-                           (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1);
+#define VDYN_SPIRAL(CSV, TRV)                                                                              \
+    hipLaunchKernelGGL((rollout_spiral_kernel<T, CSV, TRV>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral, \
+                       (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1)
+    if (shape_factors_small(p)) {
+        if (traj != nullptr) VDYN_SPIRAL(true, true); else VDYN_SPIRAL(true, false);
+    } else {
+        if (traj != nullptr) VDYN_SPIRAL(false, true); else VDYN_SPIRAL(false, false);
+    }
+#undef VDYN_SPIRAL
     return hipGetLastError();
 }
 
@@ -1446,25 +1450,28 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
             if (e_ != hipSuccess) return e_;
         }
     }
-#define VDYN_CL2(CSV, LDSV, DLV)                                                                      \
+#define VDYN_CL3(CSV, LDSV, DLV, LGV)                                                                 \
     {                                                                                                 \
         if (LDSV && wp_bytes > 64 * 1024) {                                                           \
             hipError_t e_ = hipFuncSetAttribute(                                                      \
-                reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV, DLV>),               \
+                reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV, DLV, LGV>),          \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)wp_bytes);                           \
             if (e_ != hipSuccess) return e_;                                                          \
         }                                                                                             \
-        hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV>), dim3(grid), dim3(kBlock),         \
+        hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV, LGV>), dim3(grid), dim3(kBlock),    \
                            LDSV ? wp_bytes : 0, st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0,  \
                            a.cstate0, a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.terminal,    \
                            a.cstate, a.log, a.datalog, (const T *)a.aux);                             \
     }
+#define VDYN_CL2(CSV, LDSV, DLV)                                                                      \
+    if (a.log != nullptr) VDYN_CL3(CSV, LDSV, DLV, true) else VDYN_CL3(CSV, LDSV, DLV, false)
 #define VDYN_CL(CSV, LDSV)                                                                            \
-    if (a.datalog != nullptr) VDYN_CL2(CSV, LDSV, true) else VDYN_CL2(CSV, LDSV, false)
+    if (a.datalog != nullptr) { VDYN_CL2(CSV, LDSV, true) } else { VDYN_CL2(CSV, LDSV, false) }
     if (cs && lds) { VDYN_CL(true, true) }
     else if (cs) { VDYN_CL(true, false) }
     else if (lds) { VDYN_CL(false, true) }
     else { VDYN_CL(false, false) }
+#undef VDYN_CL3
 #undef VDYN_CL2
 #undef VDYN_CL
     return hipGetLastError();
