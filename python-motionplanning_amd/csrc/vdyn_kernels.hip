@@ -163,10 +163,14 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             // two steps per trip: the control sets ping-pong (no copy) and the loop's one taken branch is paid every
             // other step
             Ctrl<T, K> c2;
-            for (; tc + 1 < tc_n; tc += 2) {
+            for (; tc + 3 < tc_n; tc += 4) {
                 fetch(c2, tc + 1);
                 eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
-                fetch(c, min(tc + 2, tc_n - 1));
+                fetch(c, tc + 2);
+                eng.template advance_state<K == 2, CS, PRE>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                fetch(c2, tc + 3);
+                eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                fetch(c, min(tc + 4, tc_n - 1));
                 eng.template advance_state<K == 2, CS, PRE>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             }
         }
