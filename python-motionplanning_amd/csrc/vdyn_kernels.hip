@@ -154,14 +154,15 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             else if (LAYOUT == 1) c.set(P, tab + (int64_t)tc * K * Pn + pid, Pn);
             else c.set(P, ctrl + ((int64_t)pid * H + t) * K, 1);
         };
-        // (Two steps per trip with the control sets ping-ponging -- no copies, state advanced in
-        // place -- was measured at the sustained clock: 0.2404 ms against 0.2376 ms for this loop.)
         Ctrl<T, K> c;
         fetch(c, 0);
         int tc = 0;
         if (!DIAG && !TRAJ) {
-            // two steps per trip: the control sets ping-pong (no copy) and the loop's one taken branch is paid every
-            // other step
+            // Four steps per trip: the control sets ping-pong (no copy), the loop's one taken branch -- tens of cycles
+            // for a lone wave -- is paid every fourth step and the scheduler overlaps a step's tail with the next
+            // one's head: 0.2011 (one per trip) -> 0.1965 (two) -> 0.1920 ms (four); eight is no faster in fp32 and
+            // 7 % slower in fp64 (48 KB of loop body against the instruction cache).  Round 1's two-per-trip attempt
+            // was slower because the step then still carried its rare path in the loop body.
             Ctrl<T, K> c2;
             for (; tc + 3 < tc_n; tc += 4) {
                 fetch(c2, tc + 1);
