@@ -251,7 +251,7 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
     const T ds = X.get(0) * h;                                    // arc length per step at the initial speed
     const T tq[4] = {torque, torque, torque, torque};
 
-    for (int t = 0; t < H; ++t) {
+    auto one_step = [&](int t) __attribute__((always_inline)) {
         T s = ds * (T)t;
         s = s < sf ? s : sf;
         T q = s * fma_t(s, fma_t(s, qd, qc), qb);
@@ -261,6 +261,18 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
         const T sd = q * cd;
         const T delta[4] = {q, q, T(0), T(0)};                     // PRE = 2: the tangent stands in for the angle
         eng.template advance_state<true, CS, 2>(P, X, delta, tq, P.mu, h, sd, cd);
+    };
+    int t = 0;
+    if (!TRAJ) {                                                   // four steps per trip (see rollout_kernel)
+        for (; t + 3 < H; t += 4) {
+            one_step(t);
+            one_step(t + 1);
+            one_step(t + 2);
+            one_step(t + 3);
+        }
+    }
+    for (; t < H; ++t) {
+        one_step(t);
         if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
             T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
 #pragma unroll
@@ -524,12 +536,19 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         T dsum = T(0);
         Ctrl<T, 2> cc;                         // step t + 1's controls are fetched behind step t (see rollout_kernel)
         if (H > 0) cc.set_pre(P, cand4 + (int64_t)c * 4);
-        for (int t = 0; t < H; ++t) {
-            Ctrl<T, 2> cn;
-            cn.set_pre(P, cand4 + ((int64_t)min(t + 1, H - 1) * C + c) * 4);
+        int t = 0;
+        Ctrl<T, 2> c2;
+        for (; t + 1 < H; t += 2) {            // two steps per trip, control sets ping-pong (see rollout_kernel)
+            c2.set_pre(P, cand4 + ((int64_t)(t + 1) * C + c) * 4);
             eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
-            cc = cn;
+            cc.set_pre(P, cand4 + ((int64_t)min(t + 2, H - 1) * C + c) * 4);
+            eng.template advance_state<true, CS, 1>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+            dsum += c2.delta[0] * c2.delta[0];
+        }
+        if (t < H) {
+            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            dsum += cc.delta[0] * cc.delta[0];
         }
         const T dx = X.get(8) - gx, dy = X.get(9) - gy;
         const T cost = sqrt_t(dx * dx + dy * dy) + w_delta * dsum;
@@ -736,7 +755,32 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     eng.init(P);
 
     int until_update = (ctrl_every - phase % ctrl_every) % ctrl_every;   // steps until (phase + t) % ctrl_every == 0
-    for (int t = 0; t < H; ++t) {
+    int t = 0;
+    if (!DATALOG && !LOG) {
+        // nothing is written per sub-step: between two controller updates the commands are held (drive.py:128), so the
+        // sub-steps in between run in a loop of their own, two per trip (see rollout_kernel)
+        while (t < H) {
+            if (until_update == 0) {
+                T steer_raw, s[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) s[i] = X.get(i);
+                controller_update<T>(G, w, s, h, c, steer_raw);
+                until_update = ctrl_every;
+            }
+            const int run = min(until_update, H - t);
+            const T delta[4] = {c.delta, c.delta, T(0), T(0)};
+            const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
+            int j = 0;
+            for (; j + 1 < run; j += 2) {
+                eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+                eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+            }
+            if (j < run) eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+            t += run;
+            until_update -= run;
+        }
+    }
+    for (; t < H; ++t) {
         if (until_update == 0) {               // wave-uniform; a countdown instead of a modulo per step
             T steer_raw, s[10];
 #pragma unroll
