@@ -8,7 +8,8 @@ evidence for the kernels that are not the headline.
 --manifest writes what summarize.py needs to normalise the counters: the kernel's name, RK4 steps
 per lane and launch, vehicle-steps per launch, algorithmic HBM bytes per launch
 and the dynamic LDS bytes the launcher asks for (rocprofv3's LDS_Block_Size column only shows the
-static part)."""
+static part).  Kernel names are PREFIXES of the demangled name (trailing template flags such as TRAJ /
+LOG select the instance the case happens to launch)."""
 import argparse
 import importlib
 import json
@@ -36,16 +37,16 @@ def build(case, pkg, torch, dev):
         s0d, tabd, pidd = (torch.from_numpy(a).to(dev) for a in (s0, tab, pid))
         if case == "headline":
             return (lambda: vm.rollout(s0d, tabd, path_id=pidd)), dict(
-                kernel="rollout_kernel<float, 2, 1, false, true>", steps_per_lane=H, vehicle_steps=n * H,
+                kernel="rollout_kernel<float, 2, 1, false, true", steps_per_lane=H, vehicle_steps=n * H,
                 algo_bytes=96 * n + tab.nbytes + 4 * n, dynamic_lds_bytes=min(H, 48 * 1024 // (7 * 2 * 4)) * 7 * 2 * 4)
         if case == "trajectory_dump":
             return (lambda: vm.rollout(s0d, tabd, path_id=pidd, traj_stride=1)), dict(
-                kernel="rollout_kernel<float, 2, 1, false, true>", steps_per_lane=H, vehicle_steps=n * H,
+                kernel="rollout_kernel<float, 2, 1, false, true", steps_per_lane=H, vehicle_steps=n * H,
                 algo_bytes=96 * n + tab.nbytes + 4 * n + 48 * n * H,
                 dynamic_lds_bytes=min(H, 48 * 1024 // (7 * 2 * 4)) * 7 * 2 * 4)
         ctrl = torch.from_numpy(W.expand_shared_controls(tab, pid)).to(dev)
         return (lambda: vm.rollout(s0d, ctrl)), dict(
-            kernel="rollout_kernel<float, 2, 0, false, true>", steps_per_lane=H, vehicle_steps=n * H,
+            kernel="rollout_kernel<float, 2, 0, false, true", steps_per_lane=H, vehicle_steps=n * H,
             algo_bytes=96 * n + 8 * n * H, dynamic_lds_bytes=0)
     if case in ("config2_f64_lane", "config2_f64_wheel"):
         H = 200
@@ -55,7 +56,7 @@ def build(case, pkg, torch, dev):
             vm = VM(2.906, np.deg2rad(30), 1e-3, device=0, lanes_per_rollout=4)
         return (lambda: vm.rollout(s2d, c2d)), dict(
             kernel=("rollout_quad_kernel<double, 2, 0, true>" if case.endswith("wheel")
-                    else "rollout_kernel<double, 2, 0, false, true>"),
+                    else "rollout_kernel<double, 2, 0, false, true"),
             steps_per_lane=H, vehicle_steps=4096 * H, algo_bytes=192 * 4096 + 16 * 4096 * H, dynamic_lds_bytes=0)
     if case == "config5_mpc":
         E, C, H = 1024, 512, 50
@@ -71,7 +72,7 @@ def build(case, pkg, torch, dev):
         Wp, P = 1024, 7
         lds = (P * (Wp + 1) * 3 + P * ((Wp + 31) // 32) * 4) * 4
         return (lambda: vm.closed_loop(cl[0], cl[1], cl[2], H, wcount=cl[3], path_id=cl[4], datalog=dl)), dict(
-            kernel=f"closed_loop_kernel<float, true, true, {'true' if dl else 'false'}>", steps_per_lane=H,
+            kernel=f"closed_loop_kernel<float, true, true, {'true' if dl else 'false'}", steps_per_lane=H,
             vehicle_steps=n * H, algo_bytes=(24 + 12) * 4 * n + 4 * n + cl[2].numel() * 4 + (180 * n * H if dl else 0),
             dynamic_lds_bytes=lds)
     if case == "spiral_lattice":
