@@ -319,8 +319,8 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     VDYN_HIP(h, hipSetDevice(h->device));
     vdyn::RolloutArgs<T> b = a;
     // 0 = automatic: wheel-parallel while it is measurably faster (tools/sweep_lanes.py at the
-    // sustained clock, against the packed lane kernel: fp32 1.6x up to 16384 rollouts, 0.94x at
-    // 24576; fp64 2.3x up to 16384, 1.46x at 32768, 1.0x at 40960)
+    // sustained clock, against the lane kernel, round 2's builds: fp32 1.42x up to 16384 rollouts, 0.84x at
+    // 24576; fp64 1.92x up to 16384, 1.17x at 32768, 0.80x at 40960)
     const int64_t auto_max = sizeof(T) == 4 ? 16384 : 32768;
     b.lanes_per_rollout = h->lanes_per_rollout == 0 ? (a.n <= auto_max ? 4 : 1) : h->lanes_per_rollout;
     VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, b, (hipStream_t)stream));
