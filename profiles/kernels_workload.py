@@ -38,12 +38,12 @@ def build(case, pkg, torch, dev):
         if case == "headline":
             return (lambda: vm.rollout(s0d, tabd, path_id=pidd)), dict(
                 kernel="rollout_kernel<float, 2, 1, false, true", steps_per_lane=H, vehicle_steps=n * H,
-                algo_bytes=96 * n + tab.nbytes + 4 * n, dynamic_lds_bytes=min(H, 48 * 1024 // (7 * 2 * 4)) * 7 * 2 * 4)
+                algo_bytes=96 * n + tab.nbytes + 4 * n, dynamic_lds_bytes=min(H, 48 * 1024 // (7 * 4 * 4)) * 7 * 4 * 4)
         if case == "trajectory_dump":
             return (lambda: vm.rollout(s0d, tabd, path_id=pidd, traj_stride=1)), dict(
                 kernel="rollout_kernel<float, 2, 1, false, true", steps_per_lane=H, vehicle_steps=n * H,
                 algo_bytes=96 * n + tab.nbytes + 4 * n + 48 * n * H,
-                dynamic_lds_bytes=min(H, 48 * 1024 // (7 * 2 * 4)) * 7 * 2 * 4)
+                dynamic_lds_bytes=min(H, 48 * 1024 // (7 * 4 * 4)) * 7 * 4 * 4)
         ctrl = torch.from_numpy(W.expand_shared_controls(tab, pid)).to(dev)
         return (lambda: vm.rollout(s0d, ctrl)), dict(
             kernel="rollout_kernel<float, 2, 0, false, true", steps_per_lane=H, vehicle_steps=n * H,

@@ -50,7 +50,10 @@ if kt:
             summary["vgpr"] = int(r["VGPR_Count"])
             summary["accum_vgpr"] = int(r["Accum_VGPR_Count"])
             summary["sgpr"] = int(r["SGPR_Count"])
-            summary["lds_bytes"] = int(r["LDS_Block_Size"])
+            summary["static_lds_bytes"] = int(r["LDS_Block_Size"])     # rocprofv3 reports the static part only
+            # dynamic LDS of the bench launch, from the launch arithmetic (vdyn_kernels.hip, launch_rollout_impl):
+            # the k = 2 control table is staged 4 wide -- (delta, torque, sin, cos) -- for P = 7 paths x H = 200 steps
+            summary["dynamic_lds_bytes"] = 7 * 4 * 4 * 200
             summary["scratch_bytes"] = int(r["Scratch_Size"])
             summary["grid"] = int(r["Grid_Size_X"])
             summary["workgroup"] = int(r["Workgroup_Size_X"])
