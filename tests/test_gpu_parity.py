@@ -252,6 +252,43 @@ def test_lds_chunking_and_large_table_paths(gpu_vm, oracle):
         assert parity(a, want, F64_TOL) <= 1e-8
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_k2_tables_with_precomputed_steering_chunks_and_remainders(gpu_vm, oracle, dtype):
+    """k = 2 shared tables are staged in LDS four wide -- (delta, torque, sin delta, cos delta), the (sin, cos) computed
+    once per table entry by the staging threads -- and the step loop runs four steps per trip.  Tables longer than one
+    LDS chunk (chunk lengths that are not multiples of four), horizons with every remainder, and a table too wide for
+    LDS must all equal the per-rollout expansion BIT FOR BIT (same functions, same order)."""
+    rng = np.random.default_rng(12)
+    vm = gpu_vm(1e-3)
+    p = oracle.default_params()
+    for P, H, n in ((40, 301, 700), (7, 203, 300), (3, 1, 100), (5, 2, 64), (9, 3, 65), (4000, 5, 900)):
+        tab = np.empty((P, H, 2))
+        tab[:, :, 0] = rng.uniform(-0.4, 0.4, (P, H))
+        tab[:, :, 1] = rng.uniform(-200, 400, (P, H))
+        pid = rng.integers(0, P, n).astype(np.int32)
+        s0 = np.zeros((12, n))
+        s0[0] = rng.uniform(10, 30, n)
+        s0[3:7] = s0[0] / 0.308309813617345
+        s0[7] = rng.uniform(-3, 3, n)
+        a = vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid)
+        b = vm.rollout(s0.astype(dtype), np.ascontiguousarray(np.transpose(tab.astype(dtype)[pid], (1, 2, 0))))
+        assert np.array_equal(a, b), (P, H, n)
+        want = oracle.rollout(p, s0, tab, 1e-3, path_id=pid, nthreads=4)
+        parity(a, want, F64_TOL if dtype == np.float64 else F32_TOL, f"P={P} H={H}")
+    # a steering angle beyond the kernel's range (|delta| > pi/4) in ONE table entry: the lanes on that path take the
+    # SAFE step there, LDS-shared == per-rollout still bit for bit
+    tab = np.zeros((3, 20, 2))
+    tab[:, :, 0], tab[:, :, 1] = 0.1, 50.0
+    tab[1, 7, 0] = 0.9
+    pid = (np.arange(200) % 3).astype(np.int32)
+    s0 = np.zeros((12, 200))
+    s0[0], s0[3:7] = 20.0, 20.0 / 0.308309813617345
+    a = vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid)
+    b = vm.rollout(s0.astype(dtype), np.ascontiguousarray(np.transpose(tab.astype(dtype)[pid], (1, 2, 0))))
+    assert np.array_equal(a, b)
+    parity(a, oracle.rollout(p, s0, tab, 1e-3, path_id=pid), F64_TOL if dtype == np.float64 else F32_TOL, "SAFE entry")
+
+
 def test_mu_max_argument_k2(gpu_vm, oracle, workloads):
     s0, ctrl = workloads.config2(8, 50)
     mu = [0.9, 0.4, 0.7, 1.0]
