@@ -62,7 +62,7 @@ def parse(argv=None):
                          "lane-per-rollout kernel to rounding, not bit for bit): the labelled second number of --strong")
     ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl",
                     help="N>1 exchange of terminal states: RCCL all-gather (default) or direct peer copies "
-                         "(hipMemcpyPeerAsync into every peer's slot on a copy stream: no CU-resident copy kernel)")
+                         "(hipMemcpyAsync into every peer's IPC-mapped slot on a copy stream: no CU-resident copy kernel)")
     ap.add_argument("--rollouts-per-gpu", type=int, default=N_PER_GPU, help=argparse.SUPPRESS)
     ap.add_argument("--horizon", type=int, default=HORIZON, help=argparse.SUPPRESS)
     ap.add_argument("--dump-durations", action="store_true", help="put every timed launch's kernel duration (ms) in the JSON")
@@ -207,6 +207,9 @@ class HipCompute:
     def __init__(self, pkg, local_rank, lanes_per_rollout, dt):
         import torch
         assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank with LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible: "
+                             "--gpus N needs N GPUs on this node")
         torch.cuda.set_device(local_rank)
         self.torch = torch
         self.device = torch.device("cuda", local_rank)

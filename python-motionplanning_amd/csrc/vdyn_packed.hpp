@@ -118,7 +118,7 @@ struct PkParams {
     f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw;
     f2 kapF, kapR;                                       // (2 - C) pi/2 per wheel (phase of the x > 1 branch, sin_c_atan2x2)
     f2 ab_F, ab_R;                                       // (+a, +a) / Izz, (-b, -b) / Izz: lever arms of the pairs
-    float hT_Izz;                                        // (T/2) / Izz
+    f2 hT_Izz;                                           // (-T/2, +T/2) / Izz: moment arms of the (left, right) longitudinal forces
     f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
     f2 neg_rw_Jw;                                        // -rw / Jw
     f2 Fz0F, Fz0R, dfxF, dfyF, dfxR, dfyR;               // static loads and load-transfer coefficients per pair (:255-258)
@@ -148,7 +148,7 @@ struct PkParams {
                 "+v"(f0r), "+v"(hT), "+v"(im), "+v"(iIz));
         rw = splat(r_w); inv_Jw = splat(iJw);
         ab_F = splat(a * iIz); ab_R = splat(-b * iIz);
-        hT_Izz = hT * iIz;
+        hT_Izz = f2{-hT * iIz, hT * iIz};
         a_negb = f2{a, -b};
         hT_side = f2{-hT, hT};
         inv_m = splat(im);
@@ -325,10 +325,12 @@ __device__ __forceinline__ f2 sincos_mid2(const PkConsts &K, float x, bool &ok)
     f2 p = fma2(K.scp[0], u2, K.scp[1]);
     p = fma2(p, u2, K.scp[2]);
     p = fma2(p, u2, K.scp[3]);                                  // (S(u), c0 + c1 u + c2 u^2 + c3 u^3 -> times u + c4 below)
-    const f2 sc = fma2(f2{r * u, u}, p, f2{r, K.cs[4].x});      // (r + r u S, 1 + u (...))
+    // the two last Horner steps as scalar fmas (the pairs (r u, u) and (r, c4) would each cost a register move)
+    const float sn = ::fmaf(r * u, p.x, r);                     // r + r u S
+    const float cs = ::fmaf(u, p.y, 9.999999404e-01f);          // c4 + u (...)
     const unsigned flip = ((unsigned)(int)k) << 31;
     ok = ok && (::fabsf(x) <= fm::kSincosMidLimit);
-    return f2{__uint_as_float(__float_as_uint(sc.x) ^ flip), __uint_as_float(__float_as_uint(sc.y) ^ flip)};
+    return f2{__uint_as_float(__float_as_uint(sn) ^ flip), __uint_as_float(__float_as_uint(cs) ^ flip)};
 }
 
 // (sin, cos) of a steering angle: no reduction inside |delta| <= pi/4 (every physical steering
@@ -405,8 +407,9 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     // :413-414: axc = U_dot - V wz, ayc = V_dot + U wz are the force sums over m; only their 1-2-2-1
     // average is ever used (:442-443), so the caller accumulates the sums and scales once
     sums_out = sums;
-    const f2 my = fma2(fyF, Q.ab_F, fyR * Q.ab_R);             // (a fy_front - b fy_rear) / Izz, per side
-    const float wzdot = (my.x + my.y) + Q.hT_Izz * (sfx.y - sfx.x);
+    f2 my = fma2(fyF, Q.ab_F, fyR * Q.ab_R);                   // (a fy_front - b fy_rear) / Izz, per side
+    my = fma2(sfx, Q.hT_Izz, my);                              // -+ T/2 fx / Izz, per side (:378, quirk Q8)
+    const float wzdot = my.x + my.y;
     k.wy = f2{wzdot, wz};
     k.wf = fma2(Q.neg_rw_Jw, fxtF, c.tqF);                     // :379-382, quirk Q2: tire-frame force in front,
     k.wr = fma2(Q.neg_rw_Jw, fxR, c.tqR);                      //           chassis-frame force at the rear
