@@ -46,6 +46,18 @@ class OracleBackedHandle:
             _view(aux, 4)[:] = o[1:5]
             _view(out, 18)[:] = o[5]
             _view(acc, 2)[:] = o[6:8]
+        elif name == "vdyn_rollout_spiral_f64_host":
+            n, H, s0, sp, wheelbase, max_steer, torque, dt, mu4, term, traj, stride = a
+            st = _view(s0, 12 * n).reshape(12, n)
+            spv = _view(sp, 3 * n).reshape(n, 3)
+            self.spiral_args = (n, H, wheelbase, max_steer, torque, dt, stride)
+            out = self.O.rollout_spiral(self.p, st, spv, H, dt, wheelbase=wheelbase, max_steer=max_steer, torque=torque,
+                                        traj_stride=stride if traj is not None and traj.value else 0)
+            if isinstance(out, tuple):
+                _view(term, 12 * n)[:] = out[0].ravel()
+                _view(traj, out[1].size)[:] = out[1].ravel()
+            else:
+                _view(term, 12 * n)[:] = out.ravel()
         elif name == "vdyn_set_option":
             pass
         else:
@@ -106,3 +118,50 @@ def test_parameter_changes_are_noticed(vm_mock, pkg):
     q = pkg.VehicleParameters(mf=1200.0)                           # a different object altogether
     c = vm.planar_model_RK4(st, [100.0] * 4, [1.0] * 4, [0.05, 0.05, 0, 0], q, 0, 0)[0]
     assert not np.array_equal(b, c)
+
+
+def test_rollout_spiral_host_marshalling(vm_mock, oracle, workloads):
+    """VehicleModel.rollout_spiral: [E][P][3] parameters are flattened ego-major, wheelbase / max_steer default to
+    the model's (VehicleModel(wheelbase, max_steer, dt), drive.py:109), shapes are validated before any call."""
+    vm, h = vm_mock
+    s0, sp = workloads.config3_spiral(21, 10, np.float64)
+    term = vm.rollout_spiral(s0, sp.reshape(3, 7, 3), 30, torque=80.0, dt=1e-3)
+    n, H, wheelbase, max_steer, torque, dt, stride = h.spiral_args
+    assert (n, H, torque, dt, stride) == (21, 30, 80.0, 1e-3, 0)
+    assert wheelbase == 2.906 and abs(max_steer - np.deg2rad(30)) < 1e-15
+    want = oracle.rollout_spiral(oracle.default_params(), s0, sp, 30, 1e-3, torque=80.0)
+    assert np.array_equal(term, want)
+    term2, traj = vm.rollout_spiral(s0, sp, 30, dt=1e-3, traj_stride=10, max_steer=0.05)
+    assert traj.shape == (3, 12, 21) and np.array_equal(traj[-1], term2) and h.spiral_args[3] == 0.05
+    for bad in (lambda: vm.rollout_spiral(s0, sp[:-1], 5), lambda: vm.rollout_spiral(s0[:10], sp, 5),
+                lambda: vm.rollout_spiral(s0, sp, -1), lambda: vm.rollout_spiral(s0, sp.reshape(7, 3, 3)[:, :, :2], 5)):
+        with pytest.raises(ValueError):
+            bad()
+
+
+def test_interpolate_waypoints_out_argument_is_validated(vm_mock):
+    vm, _ = vm_mock
+    paths = np.zeros((2, 7, 3, 49))
+    best = np.zeros(2, np.int32)
+    for wp, wc in ((np.zeros((2, 100, 2), np.float32), np.zeros(2, np.int32)),      # dtype of the call is float64
+                   (np.zeros((2, 99, 2)), np.zeros(2, np.int32)),                    # Wmax mismatch
+                   (np.zeros((2, 100, 2)), np.zeros(2, np.int64)),                   # counts must be int32
+                   (np.zeros((2, 100, 2)), np.zeros(3, np.int32))):
+        with pytest.raises(ValueError):
+            vm.interpolate_waypoints(paths, best, 0.01, 100, out=(wp, wc))
+
+
+def test_dropin_warns_like_numpy_on_nonfinite_results(vm_mock, pkg):
+    """The reference propagates inf / nan and NumPy raises a RuntimeWarning (vehicle_model.py:284-293: division
+    by a zero wheel-plane speed); so does the drop-in."""
+    import warnings
+    vm, _ = vm_mock
+    p = pkg.VehicleParameters()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        o = vm.planar_model_RK4([0.0] * 10, [0.0] * 4, [1.0] * 4, [0.0] * 4, p, 0.0, 0.0)
+    assert not np.isfinite(o[0]).all() and any(issubclass(x.category, RuntimeWarning) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        vm.planar_model_RK4([25.0, 0, 0] + [25.0 / p.rw] * 4 + [0, 0, 0], [0.0] * 4, [1.0] * 4, [0.0] * 4, p, 0.0, 0.0)
+    assert not [x for x in w if "planar_model_RK4" in str(x.message)]
