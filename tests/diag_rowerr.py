@@ -1,3 +1,6 @@
+"""Diagnostic (run by hand on a GPU box: `python tests/diag_rowerr.py`), not collected by pytest: per-row error of the
+fp32 HIP rollout and of the plain-C FLOAT oracle against the fp64 oracle on BASELINE configs[2] -- the evidence that
+the fp32 error is the reference's own fp32 floor.  Lives under tests/ because it uses oracle/."""
 import sys, importlib, numpy as np
 sys.path.insert(0, '.')
 pkg = importlib.import_module("python-motionplanning_amd")
