@@ -63,6 +63,10 @@ def parse(argv=None):
     ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl",
                     help="N>1 exchange of terminal states: RCCL all-gather (default) or direct peer copies "
                          "(hipMemcpyAsync into every peer's IPC-mapped slot on a copy stream: no CU-resident copy kernel)")
+    # rehearsal of the N > 1 path where only one GPU exists (tests/test_gpu_multishard.py): ranks share the listed
+    # devices ("0,0": both on GPU 0), torch.distributed runs on gloo (RCCL refuses two ranks on one GPU)
+    ap.add_argument("--device-map", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--rollouts-per-gpu", type=int, default=N_PER_GPU, help=argparse.SUPPRESS)
     ap.add_argument("--horizon", type=int, default=HORIZON, help=argparse.SUPPRESS)
     ap.add_argument("--dump-durations", action="store_true", help="put every timed launch's kernel duration (ms) in the JSON")
@@ -204,9 +208,11 @@ def total_rollouts(world, per_gpu, strong):
 class HipCompute:
     """The product path: VehicleModel.rollout on this rank's MI355X (HIP kernels behind the C ABI)."""
 
-    def __init__(self, pkg, local_rank, lanes_per_rollout, dt):
+    def __init__(self, pkg, local_rank, lanes_per_rollout, dt, device_map=None, dist_backend="nccl"):
         import torch
         assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+        if device_map:
+            local_rank = int(device_map.split(",")[local_rank])
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank with LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible: "
                              "--gpus N needs N GPUs on this node")
@@ -214,7 +220,8 @@ class HipCompute:
         self.torch = torch
         self.device = torch.device("cuda", local_rank)
         self.vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, device=local_rank, lanes_per_rollout=lanes_per_rollout)
-        self.backend = "nccl"
+        self.backend = dist_backend
+        self.hip = True
 
     def rollout(self, s0, tab, pid):
         return self.vm.rollout(s0, tab, path_id=pid)
@@ -254,7 +261,11 @@ def run(args, compute_factory=None):
     # lane-per-rollout on every shard: shard + gather is then bit for bit the single-GPU result
     # (SURVEY 8e); --wheel-parallel is the explicitly labelled second number for small shards
     lanes = 4 if args.wheel_parallel else 1
-    cp = (compute_factory or HipCompute)(pkg, local_rank, lanes, DT)
+    if compute_factory is None:
+        cp = HipCompute(pkg, local_rank, lanes, DT, args.device_map, args.dist_backend)
+    else:
+        cp = compute_factory(pkg, local_rank, lanes, DT)
+    on_gpu = getattr(cp, "hip", False)
     dev = cp.device
     collective = world > 1 or args.force_collective
     if collective:
@@ -382,7 +393,7 @@ def run(args, compute_factory=None):
         },
     }
     if rank == 0:
-        pmc = pmc_summary() if cp.backend == "nccl" else {}
+        pmc = pmc_summary() if on_gpu else {}
         # the binding roofline of this kernel is VALU issue, priced as 850 flop per
         # vehicle-step against the fp32 vector peak
         tf = FLOP_PER_STEP * steps_per_launch / kern_s / 1e12
@@ -420,9 +431,9 @@ def run(args, compute_factory=None):
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
             "algorithmic_bytes_per_launch": algo_bytes,
         }
-        if world == 1 and cp.backend == "nccl" and not args.no_extra and not args.strong:
+        if world == 1 and on_gpu and not args.no_extra and not args.strong:
             out["extra"] = extra_configs(cp.vm, W, torch, dev, s0, tab, pid)
-        if world == 1 and cp.backend == "nccl" and not args.no_cpu_baseline:
+        if world == 1 and on_gpu and not args.no_cpu_baseline:
             full_size = not args.strong and per_gpu == N_PER_GPU and H == HORIZON
             cb = cpu_baseline(W, term.cpu().numpy() if full_size else None)
             err = cb.pop("fp32_state_error")

@@ -88,3 +88,41 @@ def test_peer_copy_exchange_two_processes_one_gpu(tmp_path, gpu_vm, workloads, n
     for r in range(2):
         got = np.load(tmp_path / f"p2p_rank{r}.npy")
         assert got.shape == single.shape and np.array_equal(got, single)
+
+
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode):
+    """bench.py's WHOLE N > 1 path on hardware, as far as one GPU allows: `python bench.py --gpus 2` starts its two
+    ranks itself, both ranks integrate their whole-ego shard with the HIP kernel on GPU 0, the terminal blocks travel
+    through the peer-copy exchange, timing is barrier-bracketed, rank 0 prints the JSON line.  (RCCL refuses two ranks
+    on one device, so torch.distributed runs on gloo here; the RCCL exchange is rehearsed with --force-collective.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    per_gpu = 7 * 1000
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0",
+           "--no-extra", "--no-cpu-baseline", "--device-map", "0,0", "--dist-backend", "gloo", "--exchange", "p2p",
+           "--rollouts-per-gpu", str(per_gpu), "--horizon", "50", "--dump-gathered", str(tmp_path)]
+    if mode == "strong":
+        cmd.append("--strong")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    n_total = 2 * per_gpu if mode == "weak" else per_gpu
+    assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["rollouts_total"] == n_total and out["scaling"] == mode
+    assert out["shards"] == [list(workloads.shard_egos(n_total, 2, r)) for r in range(2)]
+    assert out["exchange"] == {"kind": "peer_copies", "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4,
+                               "verified": True}
+    assert out["value"] > 0 and out["roofline"]["bound"] == "valu" and "cpu_baseline" not in out
+    s0, tab, pid = workloads.config3(n_total, 50, np.float32)
+    dev = torch.device("cuda:0")
+    single = gpu_vm(1e-3).rollout(torch.from_numpy(s0).to(dev), torch.from_numpy(tab).to(dev),
+                                  path_id=torch.from_numpy(pid).to(dev)).cpu().numpy()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"gathered_rank{r}.npy"), single), "what every rank holds == the single launch"
