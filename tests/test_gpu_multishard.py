@@ -90,12 +90,14 @@ def test_peer_copy_exchange_two_processes_one_gpu(tmp_path, gpu_vm, workloads, n
         assert got.shape == single.shape and np.array_equal(got, single)
 
 
-@pytest.mark.parametrize("mode", ["weak", "strong"])
-def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode):
+@pytest.mark.parametrize("mode,exchange", [("weak", "p2p"), ("strong", "p2p"), ("weak", "rccl")])
+def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode, exchange):
     """bench.py's WHOLE N > 1 path on hardware, as far as one GPU allows: `python bench.py --gpus 2` starts its two
     ranks itself, both ranks integrate their whole-ego shard with the HIP kernel on GPU 0, the terminal blocks travel
-    through the peer-copy exchange, timing is barrier-bracketed, rank 0 prints the JSON line.  (RCCL refuses two ranks
-    on one device, so torch.distributed runs on gloo here; the RCCL exchange is rehearsed with --force-collective.)"""
+    through the exchange (peer copies, or all_gather_into_tensor on device tensors), timing is barrier-bracketed, rank 0
+    prints the JSON line.  (RCCL refuses two ranks on one device, so torch.distributed runs on gloo here -- the
+    all-gather then stages through the host, which only its speed notices; RCCL itself is rehearsed with
+    --force-collective.)"""
     import json
     import os
     import subprocess
@@ -104,7 +106,7 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     per_gpu = 7 * 1000
     cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0",
-           "--no-extra", "--no-cpu-baseline", "--device-map", "0,0", "--dist-backend", "gloo", "--exchange", "p2p",
+           "--no-extra", "--no-cpu-baseline", "--device-map", "0,0", "--dist-backend", "gloo", "--exchange", exchange,
            "--rollouts-per-gpu", str(per_gpu), "--horizon", "50", "--dump-gathered", str(tmp_path)]
     if mode == "strong":
         cmd.append("--strong")
@@ -117,8 +119,8 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
     n_total = 2 * per_gpu if mode == "weak" else per_gpu
     assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["rollouts_total"] == n_total and out["scaling"] == mode
     assert out["shards"] == [list(workloads.shard_egos(n_total, 2, r)) for r in range(2)]
-    assert out["exchange"] == {"kind": "peer_copies", "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4,
-                               "verified": True}
+    assert out["exchange"] == {"kind": "peer_copies" if exchange == "p2p" else "all_gather_into_tensor", "overlapped": True,
+                               "bytes_per_rank": 12 * (out["shards"][0][1]) * 4, "verified": True}
     assert out["value"] > 0 and out["roofline"]["bound"] == "valu" and "cpu_baseline" not in out
     s0, tab, pid = workloads.config3(n_total, 50, np.float32)
     dev = torch.device("cuda:0")
