@@ -420,13 +420,27 @@ int vdyn_nonfinite_lanes_f64_host(VdynHandle *h, int32_t rows, int64_t n, const 
 int vdyn_nonfinite_lanes_f32_host(VdynHandle *h, int32_t rows, int64_t n, const float *x, int32_t *status,
                                   int64_t *count);
 
+/* The per-handle tire fit of the fp32 step (host arithmetic only: no device, no handle needed).
+ *   sin(C atan x) / x = c W_C(c),  c = 1 / sqrt(1 + x^2),  W_C(c) = sin(C acos c) / sqrt(1 - c^2)
+ * W_C -- the Chebyshev polynomial of the second kind U_{C-1} continued to non-integer C -- is analytic on (-1, 1],
+ * so one degree-8 polynomial in c covers every slip.  coef [9] (HOST, out): its coefficients, highest degree
+ * first, as the library computes them for a handle whose wheel has shape factor C (csrc/vdyn_kernels.hip,
+ * fit_tire_wheel: interpolation at the Chebyshev nodes of [0, 1], rounded to float).  Returns VDYN_OK if the fp32
+ * Horner evaluation passed the library's own check (|error of sin(C atan x)| <= 5e-7 for every x and relative
+ * error of sin(C atan x) / x <= 5e-7 for x <= sqrt(3)) -- the fp32 lane kernels of a handle use the fit only if
+ * all four wheels pass and 0 <= C <= 2, B >= 0, and keep the atan -> sine chain otherwise -- or VDYN_ERR_ARG
+ * (coef is still filled in). */
+int vdyn_tire_fit_f32(double C, float *coef);
+
 /* Device self-test of the bounded-range elementary functions the FAST step is built from
  * (csrc/vdyn_fastmath.hpp, csrc/vdyn_packed.hpp): evaluates function `fn` on x [n] (with the scalar
  * parameter `c` where one applies) -> out0 [n], out1 [n] (second result, or untouched).
  *   fn 0 atan_rcp(x, 1/x)          1 sin_0_pi(x)           2 sin_mid(x)        3 sincos_mid(x) -> (sin, cos)
  *      4 sincos_kernel(x) -> (sin, cos)        [scalar forms, fp32 and fp64]
  *   fp32 only, the packed step's own forms:
- *      5 sin(c atan(x)), x >= 0, 0 <= c <= 2 (cosine form)   6 sincos of an unwrapped yaw -> (sin, cos)
+ *      5 the tire chain of the step (csrc/vdyn_packed.hpp, pacejka_g2x2) with the fit of C = c, any x:
+ *        -> (sin(c atan x), sin(c atan x) / x); VDYN_ERR_ARG if that C has no validated fit
+ *      6 sincos of an unwrapped yaw -> (sin, cos)
  *      7 small stage rotation -> (sin, cos)     8 steering sincos kernel -> (sin, cos)
  * tests/test_gpu_fastmath.py holds each to its stated accuracy against float64 libm.                  */
 int vdyn_fastmath_eval_f32_dev(VdynHandle *h, int32_t fn, int64_t n, const float *x, double c, float *out0,

@@ -1181,6 +1181,12 @@ vdyn::RolloutArgs<T> rollout_args(int64_t n, int32_t H, const T *state0, const T
         return fastmath_host<T>(h, fn, n, x, c, out0, out1);                                             \
     }
 
+extern "C" int vdyn_tire_fit_f32(double C, float *coef)
+{
+    if (coef == nullptr) return VDYN_ERR_ARG;
+    return vdyn::tire_fit_coefficients(C, coef) ? VDYN_OK : VDYN_ERR_ARG;   // no handle: nothing to hang a message on
+}
+
 VDYN_DEFINE_ABI(f32, float)
 VDYN_DEFINE_ABI(f64, double)
 VDYN_DEFINE_DIAG_ABI(f32, float)

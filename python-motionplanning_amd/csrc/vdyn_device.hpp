@@ -29,8 +29,21 @@ namespace vdyn {
 // Wave-uniform constants, passed by value as a kernel argument (SGPR-resident:
 // cheaper than LDS for values every lane shares).  Built on the host in double
 // from VdynParams and rounded once to T.
+// Per-wheel fit of the Pacejka shape function for the packed fp32 step (vdyn_packed.hpp, pacejka_g2x2):
+//   sin(C atan x) / x = c W_C(c),  c = cos(atan x) = 1 / sqrt(1 + x^2),  W_C(c) = sin(C acos c) / sqrt(1 - c^2).
+// W_C is the non-integer-C generalisation of the Chebyshev polynomial of the second kind: analytic on (-1, 1], its
+// only singularity at c = -1, so ONE polynomial of degree kTireFitDeg in c covers every slip from 0 to infinity
+// (c in (0, 1]) -- no argument reduction, no branch, no x > 1 case.  The coefficients depend on C, which belongs to
+// the handle: the host fits them when it builds DevParams (make_dev_params, vdyn_kernels.hip) and checks the fp32
+// Horner evaluation against double; W[i][wheel], highest degree first.  fp64 keeps the atan -> cosine chain.
+constexpr int kTireFitDeg = 8;
+template <typename T> struct TireFit {};
+template <> struct TireFit<float> {
+    float W[kTireFitDeg + 1][4];
+};
+
 template <typename T>
-struct DevParams {
+struct DevParams : TireFit<T> {
     T inv_m, inv_Izz, inv_Jw;   // 1/m, 1/Izz (vehicle_model.py:376-378), 1/Jw (:379-382)
     T a, b, half_T, rw;         // geometry (:261-271,:378), wheel radius (:284)
     T Fz0F, Fz0R;               // static normal loads (:245-248)

@@ -133,7 +133,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     Outputs18<T> o18;
     StepEngine<T> eng;
     constexpr int PRE = rollout_table_pre<K, LAYOUT, DIAG>() ? 1 : 0;
-    if (!DIAG) eng.init(P);
+    if (!DIAG) eng.template init<true, CS>(P);
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
@@ -240,7 +240,7 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
 #pragma unroll
     for (int i = 0; i < 12; ++i) X.set(i, state0[(int64_t)i * n + r]);
     StepEngine<T> eng;
-    eng.init(P);
+    eng.template init<true, CS>(P);
 
     const T p1 = spiral[3 * r], p2 = spiral[3 * r + 1], sf = spiral[3 * r + 2];
     // path_optimizer.py:149-154 with p0 = p3 = 0 (a = 0), pre-multiplied by the wheelbase: q = tan(delta)
@@ -323,7 +323,7 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);
     StepEngine<T> eng;
-    eng.template init<false>(P);   // per-lane constants
+    eng.template init<false, CS>(P);   // per-lane constants
 
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
@@ -530,7 +530,7 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
     T bc = inf;
     int bi = kNone;
     StepEngine<T> eng;
-    eng.init(P);
+    eng.template init<true, CS>(P);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         typename StepEngine<T>::State X = X0;
         T dsum = T(0);
@@ -752,7 +752,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     w.ss = w.bs = WPLDS ? 1 : Pn;
     w.W = min(max(wcount[pid], 1), Wmax);
     StepEngine<T> eng;
-    eng.init(P);
+    eng.template init<true, CS>(P);
 
     int until_update = (ctrl_every - phase % ctrl_every) % ctrl_every;   // steps until (phase + t) % ctrl_every == 0
     int t = 0;
@@ -1172,7 +1172,8 @@ template <> struct FmSel<double> {
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, T *__restrict__ out0, T *__restrict__ out1)
+fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, TireFit<float> fit, T *__restrict__ out0,
+                     T *__restrict__ out1)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     PkConsts K;
@@ -1192,13 +1193,17 @@ fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, T *__restr
         if (sizeof(T) == 4) {
             const float vf = (float)v;
             if (fn == 5) {
-                const f2 C2[2] = {splat((float)c), splat((float)c)};
-                const float kap = (2.0f - (float)c) * 1.57079637050628662109375f;
-                const f2 k2[2] = {splat(kap), splat(kap)}, xs[2] = {splat(vf), splat(vf)};
-                const f2 ix[2] = {splat(fm::rcp(vf)), splat(fm::rcp(vf))};
+                // the FAST step's tire chain: x sin(C atan x) / x through pacejka_g2x2 with the fit of C = c
+                f2 w[kTireFitDeg + 1];
+#pragma unroll
+                for (int j = 0; j <= kTireFitDeg; ++j) w[j] = f2{fit.W[j][0], fit.W[j][1]};
+                const f2 *const Wq[2] = {w, w};
+                const f2 q1[2] = {splat(::fmaf(vf, vf, 1.0f)), splat(::fmaf(vf, vf, 1.0f))};
+                const f2 sc[2] = {f2{vf, 1.0f}, f2{vf, 1.0f}};           // (x G, G)
                 f2 o[2];
-                sin_c_atan2x2<true>(K, C2, k2, xs, ix, o);
+                pacejka_g2x2(Wq, q1, sc, o);
                 a = (T)o[0].x;
+                b = (T)o[0].y; two = true;
             } else if (fn == 6) {
                 bool ok = true;
                 const f2 r = sincos_mid2(K, vf, ok);
@@ -1219,10 +1224,92 @@ fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, T *__restr
 
 // ---------------------------------------------------------------- launchers ---------
 
+// ---- the handle's tire fit (TireFit in vdyn_device.hpp) ---------------------------------------
+// W_C(c) = sin(C acos c) / sqrt(1 - c^2) on c in [0, 1], in double.
+static double tire_w_exact(double C, double c)
+{
+    const double th = std::acos(std::min(1.0, std::max(-1.0, c)));
+    if (th < 1e-4) return C * (1.0 + (1.0 - C * C) * th * th / 6.0);       // sin(C th) / sin(th), both expanded
+    return std::sin(C * th) / std::sin(th);
+}
+
+// Degree-kTireFitDeg interpolant of W_C at the Chebyshev nodes of [0, 1] (within a small factor of the minimax
+// polynomial; what limits the result is the fp32 Horner evaluation, not the fit), as monomial coefficients in c,
+// highest degree first, rounded to float.  Then the check: the fp32 Horner value against double on 4097 points --
+// absolute error of mu / D = sin(C atan x) below 5e-7 everywhere, relative error of G = sin(C atan x) / x (the
+// cornering / longitudinal stiffness at small slip) below 5e-7 for x <= sqrt(3).  False if the check fails.
+static bool fit_tire_wheel(double C, float W[kTireFitDeg + 1])
+{
+    constexpr int n = kTireFitDeg + 1;
+    const double pi = 3.14159265358979323846;
+    double f[n], a[n];
+    for (int k = 0; k < n; ++k) f[k] = tire_w_exact(C, 0.5 * (std::cos(pi * (2 * k + 1) / (2.0 * n)) + 1.0));
+    for (int j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += f[k] * std::cos(pi * j * (2 * k + 1) / (2.0 * n));
+        a[j] = acc * (j == 0 ? 1.0 : 2.0) / n;
+    }
+    // sum_j a_j T_j(2 c - 1) as a polynomial in c: T_0 = 1, T_1 = z, T_{j+1} = 2 z T_j - T_{j-1}, z = 2 c - 1
+    double t0[n] = {1.0}, t1[n] = {-1.0, 2.0}, m[n] = {0.0};
+    for (int i = 0; i < n; ++i) m[i] = a[0] * t0[i] + (n > 1 ? a[1] * t1[i] : 0.0);
+    for (int j = 2; j < n; ++j) {
+        double t2[n];
+        for (int i = 0; i < n; ++i) t2[i] = 2.0 * ((i > 0 ? 2.0 * t1[i - 1] : 0.0) - t1[i]) - t0[i];
+        for (int i = 0; i < n; ++i) { m[i] += a[j] * t2[i]; t0[i] = t1[i]; t1[i] = t2[i]; }
+    }
+    for (int i = 0; i < n; ++i) W[i] = (float)m[n - 1 - i];
+    if (!std::isfinite(C)) return false;
+    for (int i = 0; i <= 4096; ++i) {
+        const float c = (float)i / 4096.0f;
+        float g = std::fmaf(W[0], c, W[1]);
+        for (int k = 2; k < n; ++k) g = std::fmaf(g, c, W[k]);
+        const double want = tire_w_exact(C, (double)c), err = std::fabs((double)g - want);
+        if (!(err * std::sqrt(std::max(0.0, 1.0 - (double)c * c)) <= 5e-7)) return false;
+        if (c >= 0.5f && !(err <= 5e-7 * std::max(std::fabs(want), 1e-30))) return false;
+    }
+    return true;
+}
+
+struct TireFitHost {
+    double C[4];
+    float W[kTireFitDeg + 1][4];
+    bool ok, filled;
+};
+
+// The fit of a handle's four shape factors; the last one computed is kept per thread (a launch per 0.2 ms must not
+// refit: the key is C alone, B does not enter W_C).
+static const TireFitHost &tire_fit(const VdynParams &p)
+{
+    static thread_local TireFitHost cache = {{0, 0, 0, 0}, {{0}}, false, false};
+    if (cache.filled && cache.C[0] == p.C[0] && cache.C[1] == p.C[1] && cache.C[2] == p.C[2] && cache.C[3] == p.C[3])
+        return cache;
+    cache.ok = true;
+    for (int w = 0; w < 4; ++w) {
+        float col[kTireFitDeg + 1];
+        int same = -1;
+        for (int v = 0; v < w; ++v)
+            if (p.C[v] == p.C[w]) same = v;
+        if (same >= 0) {
+            for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = cache.W[i][same];
+            continue;
+        }
+        const bool ok = fit_tire_wheel(p.C[w], col);
+        cache.ok = cache.ok && ok;
+        for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = col[i];
+    }
+    for (int w = 0; w < 4; ++w) cache.C[w] = p.C[w];
+    cache.filled = true;
+    return cache;
+}
+
 template <typename T>
 DevParams<T> make_dev_params(const VdynParams &p, const double *mu4)
 {
     DevParams<T> d;
+    if constexpr (std::is_same<T, float>::value) {
+        const TireFitHost &f = tire_fit(p);
+        std::memcpy(d.W, f.W, sizeof(d.W));
+    }
     d.inv_m = (T)(1.0 / p.m);
     d.inv_Izz = (T)(1.0 / p.Izz);
     d.inv_Jw = (T)(1.0 / p.Jw);
@@ -1250,6 +1337,16 @@ static bool shape_factors_small(const VdynParams &p)
 {
     for (int i = 0; i < 4; ++i)
         if (!(p.C[i] >= 0.0 && p.C[i] <= 2.0 && p.B[i] >= 0.0)) return false;
+    return true;
+}
+
+// The CS flag of the lane-per-rollout kernels: shape factors in the short-form range and, in fp32 (whose FAST step
+// then runs the handle's fitted tire chain), a fit that passed its check.
+template <typename T>
+static bool lane_cs(const VdynParams &p)
+{
+    if (!shape_factors_small(p)) return false;
+    if (std::is_same<T, float>::value) return tire_fit(p).ok;
     return true;
 }
 
@@ -1307,7 +1404,7 @@ void build_fleet_table(const VdynParams *classes, int V, const double *mu4, T *o
     for (int v = 0; v < V; ++v) {
         const DevParams<T> d = make_dev_params<T>(classes[v], mu4);
         std::memcpy(out + (size_t)v * dev_params_len<T>(), &d, sizeof(d));
-        *all_small = *all_small && shape_factors_small(classes[v]);
+        *all_small = *all_small && lane_cs<T>(classes[v]);
     }
 }
 template <typename T> int fleet_table_len(int V) { return V * dev_params_len<T>(); }
@@ -1358,11 +1455,11 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     // one step of the table must fit the LDS budget (k = 2 tables are staged 4 wide, see rollout_table_pre)
     if (layout == VDYN_CTRL_SHARED && (size_t)a.P * (a.k == 2 ? 4 : a.k) * sizeof(T) > (size_t)kLdsBudget) layout = 2;
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
-    const bool cs = shape_factors_small(p);
+    const bool cs = lane_cs<T>(p), cs_quad = shape_factors_small(p);   // the wheel-parallel step keeps the atan chain
     if (a.lanes_per_rollout == 4 && !diag) {
 #define VDYN_DISPATCH_Q(KK, LL)                                                        \
     if (a.k == KK && layout == LL)                                                     \
-        return cs ? launch_rollout_quad_impl<T, KK, LL, true>(p, a, st)                \
+        return cs_quad ? launch_rollout_quad_impl<T, KK, LL, true>(p, a, st)                \
                   : launch_rollout_quad_impl<T, KK, LL, false>(p, a, st);
         VDYN_DISPATCH_Q(2, 0)
         VDYN_DISPATCH_Q(2, 1)
@@ -1399,7 +1496,7 @@ hipError_t launch_rollout_spiral(const VdynParams &p, int64_t n, int H, const T 
 #define VDYN_SPIRAL(CSV, TRV)                                                                              \
     hipLaunchKernelGGL((rollout_spiral_kernel<T, CSV, TRV>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral, \
                        (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1)
-    if (shape_factors_small(p)) {
+    if (lane_cs<T>(p)) {
         if (traj != nullptr) VDYN_SPIRAL(true, true); else VDYN_SPIRAL(true, false);
     } else {
         if (traj != nullptr) VDYN_SPIRAL(false, true); else VDYN_SPIRAL(false, false);
@@ -1421,8 +1518,18 @@ template <typename T>
 hipError_t launch_fastmath_eval(int fn, int64_t n, const T *x, double c, T *out0, T *out1, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
+    TireFit<float> fit;
+    std::memset(&fit, 0, sizeof(fit));
+    if (fn == 5) {
+        VdynParams p;
+        std::memset(&p, 0, sizeof(p));
+        for (int w = 0; w < 4; ++w) p.C[w] = c;
+        const TireFitHost &f = tire_fit(p);
+        if (!f.ok) return hipErrorInvalidValue;            // no validated fit for this C: the step would not use it either
+        std::memcpy(fit.W, f.W, sizeof(fit.W));
+    }
     hipLaunchKernelGGL((fastmath_eval_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, fn, n, x,
-                       (T)c, out0, out1);
+                       (T)c, fit, out0, out1);
     return hipGetLastError();
 }
 
@@ -1455,7 +1562,7 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
     }
     int block = ((C + 63) / 64) * 64;
     block = std::max(64, std::min(block, mpc_block_max<T>()));
-    if (shape_factors_small(p))
+    if (lane_cs<T>(p))
         hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
                            C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
     else
@@ -1492,7 +1599,7 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     // gfx950 has 160 KiB of LDS per CU; a workgroup may take all of it (one workgroup per
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
     const bool lds = wp_bytes <= kClosedLoopLdsBudget;
-    const bool cs = shape_factors_small(p);
+    const bool cs = lane_cs<T>(p);
     if (a.aux == nullptr && lds) return hipErrorInvalidValue;       // the LDS image is not optional
     if (a.aux != nullptr) {
         const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
@@ -1640,6 +1747,7 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
 // compile in parallel and with the instruction-scheduling strategy that suits each (_build.py).
 #if !defined(VDYN_ONLY_F64)
 VDYN_INSTANTIATE(float)
+bool tire_fit_coefficients(double C, float *coef) { return fit_tire_wheel(C, coef); }
 #endif
 #if !defined(VDYN_ONLY_F32)
 VDYN_INSTANTIATE(double)

@@ -10,9 +10,9 @@
 // products, and the ten states advance as five pairs.
 //
 // What cannot be packed stays scalar on the halves of a pair: v_rcp / v_rsq, min / max, |x|.
-// Compares and selects are avoided altogether (clamp indicator, pk_above_one).  Polynomial
-// coefficients live in VGPR pairs for the whole kernel (VOP3P takes no literal constants on
-// gfx9); PkConsts::init pins them there.
+// The tire chain of the FAST step has no compare, select or argument reduction at all (pacejka_g2x2).
+// Polynomial coefficients live in VGPR pairs for the whole kernel (VOP3P takes no literal constants
+// on gfx9); PkConsts::init and PkParams::init pin them there.
 //
 // Semantics are those of vdyn_device.hpp (same formulas, same quirk handling); only the order
 // of the four-tire sums differs ((FL+RL)+(FR+RR) instead of ((FL+FR)+RL)+RR).
@@ -38,14 +38,6 @@ __device__ __forceinline__ f2 pk_cross(f2 a, f2 b)        // (a.y b.x, -a.x b.x)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ f2 pk_above_one(f2 x, f2 big)  // per half: 1.0f if x > 1 else 0.0f   (big = 2^100)
-{
-    // (x - 1) 2^100 clamped to [0, 1]: the smallest x above 1 already gives 2^77, so the result is
-    // exactly 0 or 1 for every float (NaN -> 0)
-    f2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %2 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp" : "=v"(r) : "v"(x), "v"(big));
-    return r;
-}
 __device__ __forceinline__ f2 pk_hi_conj(f2 a, f2 b)      // (-a.y b.x, a.y b.y)
 {
     f2 r;
@@ -58,35 +50,38 @@ __device__ __forceinline__ f2 pk_hi_conj(f2 a, f2 b)      // (-a.y b.x, a.y b.y)
 struct PkConsts {
     f2 at[8];            // atan(t) = t Q(t^2) on [0, 1]: q7 .. q0 (tools/fit_polys.py, degree 7: 2.3e-7 relative)
     f2 sn[4];            // sin on [-pi/2, pi/2]: the four coefficients of sin_mid / sin_0_pi
-    f2 pi_hi, pi_lo, inv_pi, pio2;
-    f2 big, neg2, tiny;  // 2^100 (indicator scale), -2, 1e-30 (floor of s^2, quirk Q5)
+    f2 pi_hi, pi_lo, inv_pi;
+    f2 neg2, tiny;       // -2, 1e-30 (floor of s^2, quirk Q5)
     f2 side;             // (-1, +1): left / right wheel (quirk Q8)
     f2 sck[3];           // (sin, cos) kernel coefficients on |r| <= pi/4 (sincos_kernel), one pair per degree
-    f2 cs[5];            // cos(z) = Q(z^2) on |z| <= pi/2, highest degree first (CS: sin(y) = cos(y - pi/2), y in [0, pi])
     f2 rot_a, rot_b, rot_c;   // (-1/6, 1/24), (1, -1/2), (0, 1): (sin d, cos d) of a stage's small yaw increment
-    f2 scp[4];           // (sin, cos) on |r| <= pi/2 in one chain: (sn[i], cs[i]) pairs (sincos_mid2)
+    f2 scp[4];           // (sin, cos) on |r| <= pi/2 in one chain: (sin, cos) coefficient pairs (sincos_mid2)
 
     __device__ __forceinline__ void pin(f2 &v, float c)
     {
         v = splat(c);
         asm volatile("" : "+v"(v));
     }
+    // FIT: the tire chain is pacejka_g2x2 -- the atan / cosine coefficients are not needed (and not pinned)
+    template <bool FIT = false>
     __device__ __forceinline__ void init()
     {
         const float a[8] = {-4.729942884e-03f, 2.439327165e-02f, -5.969851837e-02f, 9.930104017e-02f,
                             -1.402552277e-01f, 1.997082233e-01f, -3.333206475e-01f, 9.999998808e-01f};
         const float s[4] = {2.607052693e-06f, -1.981028618e-04f, 8.333077654e-03f, -1.666665971e-01f};
+        if (!FIT) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pin(at[i], a[i]);
+            for (int i = 0; i < 8; ++i) pin(at[i], a[i]);
+        }
+        if (!FIT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pin(sn[i], s[i]);
-        pin(pi_hi, 3.1415927410125732421875f);
-        pin(pi_lo, -8.74227800037248566e-08f);
-        pin(inv_pi, 0.318309886183790671538f);
-        pin(pio2, 1.57079637050628662109375f);
-        pin(big, 0x1p100f);
+            for (int i = 0; i < 4; ++i) pin(sn[i], s[i]);
+            pin(pi_hi, 3.1415927410125732421875f);
+            pin(pi_lo, -8.74227800037248566e-08f);
+            pin(inv_pi, 0.318309886183790671538f);
+            pin(tiny, 1e-30f);
+        }
         pin(neg2, -2.0f);
-        pin(tiny, 1e-30f);
         side = f2{-1.0f, 1.0f};
         asm volatile("" : "+v"(side));
         const float sks[3] = {-1.951163867e-04f, 8.332134224e-03f, -1.666665375e-01f};
@@ -99,8 +94,6 @@ struct PkConsts {
         // cos(z) on |z| <= pi/2 as a degree-4 polynomial in z^2 (tools/fit_polys.py: fit error 5.1e-8,
         // fp32 Horner within 1.8e-7 absolute)
         const float cc[5] = {2.312937249e-05f, -1.385257230e-03f, 4.166342318e-02f, -4.999989867e-01f, 9.999999404e-01f};
-#pragma unroll
-        for (int i = 0; i < 5; ++i) pin(cs[i], cc[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             scp[i] = f2{s[i], cc[i]};
@@ -116,25 +109,28 @@ struct PkConsts {
 // Vehicle constants as pairs (front axle pair F = (FL, FR), rear pair R = (RL, RR)).
 struct PkParams {
     f2 BF, BR, invBF, invBR, CF, CR, rw, inv_Jw;
-    f2 kapF, kapR;                                       // (2 - C) pi/2 per wheel (phase of the x > 1 branch, sin_c_atan2x2)
     f2 ab_F, ab_R;                                       // (+a, +a) / Izz, (-b, -b) / Izz: lever arms of the pairs
     f2 hT_Izz;                                           // (-T/2, +T/2) / Izz: moment arms of the (left, right) longitudinal forces
     f2 a_negb, hT_side, inv_m;                           // (a, -b); (-T/2, +T/2); (1/m, 1/m)
     f2 neg_rw_Jw;                                        // -rw / Jw
     f2 Fz0F, Fz0R, dfxF, dfyF, dfxR, dfyR;               // static loads and load-transfer coefficients per pair (:255-258)
+    f2 fwF[kTireFitDeg + 1], fwR[kTireFitDeg + 1];       // W_C(c) per wheel (TireFit), highest degree first (FIT only)
     // UNIFORM: P is the same for every lane (a by-value kernel argument, in SGPRs); otherwise it was
     // read per lane (heterogeneous fleet, VGPRs).
-    template <bool UNIFORM>
+    template <bool UNIFORM, bool FIT = false>
     __device__ __forceinline__ void init(const DevParams<float> &P)
     {
+        if (FIT) {
+#pragma unroll
+            for (int i = 0; i <= kTireFitDeg; ++i) {
+                fwF[i] = f2{P.W[i][0], P.W[i][1]};
+                fwR[i] = f2{P.W[i][2], P.W[i][3]};
+                asm volatile("" : "+v"(fwF[i]), "+v"(fwR[i]));   // nine pairs per axle, read at every stage: VGPRs
+            }
+        }
         BF = f2{P.B[0], P.B[1]}; BR = f2{P.B[2], P.B[3]};
         invBF = f2{P.invB[0], P.invB[1]}; invBR = f2{P.invB[2], P.invB[3]};
         CF = f2{P.C[0], P.C[1]}; CR = f2{P.C[2], P.C[3]};
-        {
-            const float hp = 1.57079637050628662109375f;
-            kapF = f2{(2.0f - P.C[0]) * hp, (2.0f - P.C[1]) * hp};
-            kapR = f2{(2.0f - P.C[2]) * hp, (2.0f - P.C[3]) * hp};
-        }
         // Scalars first, each behind a zero-instruction barrier: left visible as neighbouring struct
         // fields, pairs of them are fetched with one 8-byte read, and because such reads overlap
         // (inv_Jw|a, a|b) the compiler then parks that part of the by-value struct in scratch.
@@ -167,50 +163,24 @@ struct PkParams {
 // pair's independent instruction is exactly the filler that makes the padding unnecessary.
 #define VDYN_BOTH(q) _Pragma("unroll") for (int q = 0; q < 2; ++q)
 
-// sin(C atan(x)) for both pairs; inv_x = 1/x per half.
-// kappa = (2 - C) pi/2 per half (CS only).
-template <bool CS>
-__device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], const f2 kappa[2], const f2 x[2],
-                                              const f2 inv_x[2], f2 out[2])
+// sin(C atan(x)) for both pairs, any C and any sign of x (handles without a validated fit); inv_x = 1/x per half.
+__device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], const f2 x[2], const f2 inv_x[2],
+                                              f2 out[2])
 {
     // atan_rcp on all four halves: selects scalar, Horner chain packed
     bool b0[2], b1[2];
-    f2 t[2], u[2], p[2], th[2], y[2], r[2], w[2], ps[2], kk[2], ind[2];
-    if (CS) {
-        // CS implies B >= 0, hence x = B s >= 0: the reduced argument is min(x, 1/x) and
-        // atan(x) = p + [x > 1] (pi/2 - 2 p), no compare, no select, no sign to carry
-        VDYN_BOTH(q) t[q] = f2{::fminf(x[q].x, inv_x[q].x), ::fminf(x[q].y, inv_x[q].y)};
-        VDYN_BOTH(q) ind[q] = pk_above_one(x[q], K.big);
-    } else {
-        VDYN_BOTH(q) { b0[q] = ::fabsf(x[q].x) > 1.0f; b1[q] = ::fabsf(x[q].y) > 1.0f; }
-        VDYN_BOTH(q) t[q] = f2{b0[q] ? inv_x[q].x : x[q].x, b1[q] ? inv_x[q].y : x[q].y};
-    }
+    f2 t[2], u[2], p[2], th[2], y[2], r[2], w[2], ps[2], kk[2];
+    VDYN_BOTH(q) { b0[q] = ::fabsf(x[q].x) > 1.0f; b1[q] = ::fabsf(x[q].y) > 1.0f; }
+    VDYN_BOTH(q) t[q] = f2{b0[q] ? inv_x[q].x : x[q].x, b1[q] ? inv_x[q].y : x[q].y};
     VDYN_BOTH(q) u[q] = t[q] * t[q];
     VDYN_BOTH(q) p[q] = K.at[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) VDYN_BOTH(q) p[q] = fma2(p[q], u[q], K.at[i]);
     VDYN_BOTH(q) p[q] = p[q] * t[q];
-    if (!CS) {
+    {
         const float pio2 = 1.57079637050628662109375f;
         VDYN_BOTH(q) th[q] = f2{b0[q] ? (::copysignf(pio2, x[q].x) - p[q].x) : p[q].x,
                                b1[q] ? (::copysignf(pio2, x[q].y) - p[q].y) : p[q].y};
-    }
-    if (CS) {
-        // y = C theta lies in [0, pi]: sin(y) = cos(y - pi/2), an even polynomial in z = y - pi/2 on
-        // |z| <= pi/2 -- no reflection, no min, and z comes out of the fma that forms y.  Absolute
-        // accuracy 1.8e-7 (the reflected odd polynomial was 2 ulp relative): the force it scales,
-        // s_x mu Fz / s, inherits an absolute error of 2e-7 Fz ~ 1e-3 N per tire.
-        // theta = p (x <= 1) or pi/2 - p (x > 1), and cos is even: cos(C theta - pi/2) = cos(C p - phi) with
-        // phi = pi/2 or (C - 1) pi/2 = pi/2 - [x > 1] (2 - C) pi/2
-        f2 z[2], q4[2], phi[2];
-        VDYN_BOTH(q) phi[q] = fma2(ind[q], -kappa[q], K.pio2);
-        VDYN_BOTH(q) z[q] = fma2(C[q], p[q], -phi[q]);
-        VDYN_BOTH(q) w[q] = z[q] * z[q];
-        VDYN_BOTH(q) q4[q] = fma2(K.cs[0], w[q], K.cs[1]);
-        VDYN_BOTH(q) q4[q] = fma2(q4[q], w[q], K.cs[2]);
-        VDYN_BOTH(q) q4[q] = fma2(q4[q], w[q], K.cs[3]);
-            VDYN_BOTH(q) out[q] = fma2(q4[q], w[q], K.cs[4]);
-        return;
     }
     VDYN_BOTH(q) y[q] = C[q] * th[q];
     {
@@ -233,17 +203,34 @@ __device__ __forceinline__ void sin_c_atan2x2(const PkConsts &K, const f2 C[2], 
     }
 }
 
+// G(x) = sin(C atan x) / x for both pairs from 1 + x^2 (x = B s, any sign of B: G is even in x):
+// c = rsq(1 + x^2), G = c W_C(c) with the handle's own polynomial (TireFit in vdyn_device.hpp).  Eight packed
+// fmas and one multiply per pair for every slip -- the chain it replaces (x and 1/x from rsq(s^2), min, indicator,
+// degree-7 atan, phase, degree-4 cosine) took 21.  x = 0 needs no special case (quirk Q5: G(0) = C, and the
+// reference's s == 0 branch returns what s -> 0 gives); x = inf gives c = 0, G = 0.  Returns c W_C(c) * scale.
+__device__ __forceinline__ void pacejka_g2x2(const f2 *const W[2], const f2 q1[2], const f2 scale[2], f2 out[2])
+{
+    f2 c[2], g[2], cm[2];
+    VDYN_BOTH(q) c[q] = f2{fm::rsq(q1[q].x), fm::rsq(q1[q].y)};
+    VDYN_BOTH(q) g[q] = fma2(W[q][0], c[q], W[q][1]);
+#pragma unroll
+    for (int i = 2; i <= kTireFitDeg; ++i) VDYN_BOTH(q) g[q] = fma2(g[q], c[q], W[q][i]);
+    VDYN_BOTH(q) cm[q] = c[q] * scale[q];                      // beside the Horner chain, not behind it
+    VDYN_BOTH(q) out[q] = g[q] * cm[q];
+}
+
 // All four tires (vehicle_model.py:274-373, as tire_force in vdyn_device.hpp): index 0 = front
 // pair (always steered), index 1 = rear pair (steered only with k = 12 controls).
-// CS (B >= 0): the slips are carried pre-multiplied by B -- x = B s comes out of the same rsq that
-// normalises the slip, 1/x is that rsq itself, and B cancels in s_x mu / s = (B s_x) sin(C atan x) / x.
+// CS (0 <= C <= 2, B >= 0 and the handle's fit validated): the slips are carried pre-multiplied by B and
+// s_x mu / s = (B s_x) G(B s) comes from pacejka_g2x2 -- no 1/s, no s at all.
 // s[] (DIAG only) is the combined slip itself.
 template <bool REAR_STEERED, bool CS, bool DIAG>
-__device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], const f2 invB[2], const f2 C[2],
-                                              const f2 kappa[2], f2 rw, f2 vxc, const f2 vyc[2], const f2 w[2],
-                                              const f2 cd[2], const f2 sd[2], const f2 muFz[2], f2 fx[2], f2 fy[2],
-                                              f2 fxt[2], f2 fyt[2], f2 s[2])
+__device__ __forceinline__ void tire_force2x2(const PkConsts &K, const PkParams &Q, f2 vxc, const f2 vyc[2],
+                                              const f2 w[2], const f2 cd[2], const f2 sd[2], const f2 muFz[2], f2 fx[2],
+                                              f2 fy[2], f2 fxt[2], f2 fyt[2], f2 s[2])
 {
+    const f2 B[2] = {Q.BF, Q.BR}, invB[2] = {Q.invBF, Q.invBR}, C[2] = {Q.CF, Q.CR};
+    const f2 rw = Q.rw;
     f2 vx[2], vy[2], rvx[2], sx[2], sy[2], s2[2], rs[2], xs[2], ix[2], g[2], tmp[2];
     tmp[0] = vyc[0] * sd[0];
     vx[0] = fma2(vxc, cd[0], tmp[0]);
@@ -263,24 +250,30 @@ __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const f2 B[2], 
     VDYN_BOTH(q) sx[q] = fma2(rw, w[q], -vx[q]);
     VDYN_BOTH(q) sx[q] = sx[q] * rvx[q];
     VDYN_BOTH(q) sy[q] = f2{-vy[q].x * ::fabsf(rvx[q].x), -vy[q].y * ::fabsf(rvx[q].y)};          // quirk Q4
-    // quirk Q5: s == 0 takes the fallback branch in the reference, whose value is what the regular
-    // formula yields for s -> 0; s^2 + 1e-30 keeps rsq finite there and is s^2 to the last bit
-    // wherever s^2 >= 1e-22 (below that the force is linear in slip and does not see s at all)
-    VDYN_BOTH(q) s2[q] = fma2(sy[q], sy[q], K.tiny);
-    VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);
-    VDYN_BOTH(q) rs[q] = f2{fm::rsq(s2[q].x), fm::rsq(s2[q].y)};
     if (CS) {
-        VDYN_BOTH(q) xs[q] = s2[q] * rs[q];                     // x = B s
-        sin_c_atan2x2<CS>(K, C, kappa, xs, rs, g);
-        if (DIAG) VDYN_BOTH(q) s[q] = xs[q] * invB[q];
+        const f2 *const Wq[2] = {Q.fwF, Q.fwR};
+        const f2 one = splat(1.0f);
+        VDYN_BOTH(q) s2[q] = fma2(sy[q], sy[q], one);
+        VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);                                           // 1 + (B s)^2
+        pacejka_g2x2(Wq, s2, muFz, g);
+        if (DIAG) {
+            VDYN_BOTH(q) xs[q] = fma2(sx[q], sx[q], sy[q] * sy[q]);
+            VDYN_BOTH(q) s[q] = f2{__builtin_sqrtf(xs[q].x), __builtin_sqrtf(xs[q].y)} * invB[q];
+        }
     } else {
+        // quirk Q5: s == 0 takes the fallback branch in the reference, whose value is what the regular
+        // formula yields for s -> 0; s^2 + 1e-30 keeps rsq finite there and is s^2 to the last bit
+        // wherever s^2 >= 1e-22 (below that the force is linear in slip and does not see s at all)
+        VDYN_BOTH(q) s2[q] = fma2(sy[q], sy[q], K.tiny);
+        VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);
+        VDYN_BOTH(q) rs[q] = f2{fm::rsq(s2[q].x), fm::rsq(s2[q].y)};
         VDYN_BOTH(q) s[q] = s2[q] * rs[q];
         VDYN_BOTH(q) xs[q] = B[q] * s[q];
         VDYN_BOTH(q) ix[q] = rs[q] * invB[q];
-        sin_c_atan2x2<CS>(K, C, kappa, xs, ix, g);
+        sin_c_atan2x2(K, C, xs, ix, g);
+        VDYN_BOTH(q) g[q] = g[q] * rs[q];
+        VDYN_BOTH(q) g[q] = g[q] * muFz[q];
     }
-    VDYN_BOTH(q) g[q] = g[q] * rs[q];
-    VDYN_BOTH(q) g[q] = g[q] * muFz[q];
     VDYN_BOTH(q) fxt[q] = sx[q] * g[q];
     VDYN_BOTH(q) fyt[q] = sy[q] * g[q];
     tmp[0] = fyt[0] * sd[0];
@@ -385,11 +378,10 @@ __device__ __forceinline__ void planar_deriv2(const DevParams<float> &P, const P
     const f2 U2 = f2{U, U}, V2 = f2{V, V}, wz2 = f2{wz, wz};
     const f2 vxc = fma2(Q.hT_side, wz2, U2);                  // :261-271 (left, right), both axles (quirk Q8)
     const f2 vyb = fma2(Q.a_negb, wz2, V2);                   // (V + a wz, V - b wz): front, rear
-    const f2 Bq[2] = {Q.BF, Q.BR}, iBq[2] = {Q.invBF, Q.invBR}, Cq[2] = {Q.CF, Q.CR}, kq[2] = {Q.kapF, Q.kapR};
     const f2 vyq[2] = {f2{vyb.x, vyb.x}, f2{vyb.y, vyb.y}}, wq[2] = {s.wf, s.wr};
     const f2 cdq[2] = {c.cdF, c.cdR}, sdq[2] = {c.sdF, c.sdR}, mfq[2] = {c.muFzF, c.muFzR};
     f2 fxq[2], fyq[2], fxtq[2], fytq[2], slq[2];
-    tire_force2x2<!K2, CS, DIAG>(K, Bq, iBq, Cq, kq, Q.rw, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq, slq);
+    tire_force2x2<!K2, CS, DIAG>(K, Q, vxc, vyq, wq, cdq, sdq, mfq, fxq, fyq, fxtq, fytq, slq);
     if (DIAG) {
         dg->fx[0] = fxq[0]; dg->fx[1] = fxq[1];
         dg->fy[0] = fyq[0]; dg->fy[1] = fyq[1];
@@ -551,7 +543,7 @@ struct StepEngine {
     {
         rk4_advance<T, K2, false, CS, PRE>(P, X.s, X.ax, X.ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
     }
-    template <bool UNIFORM = true>
+    template <bool UNIFORM = true, bool FIT = false>
     __device__ __forceinline__ void init(const DevParams<T> &) {}
     __device__ __forceinline__ void steer_sincos(T d, T &sd, T &cd) const
     {
@@ -577,11 +569,12 @@ template <>
 struct StepEngine<float> {
     PkConsts K;
     PkParams Q;
-    template <bool UNIFORM = true>
+    // FIT: the kernel's CS flag -- the step then takes the handle's fitted tire chain (pacejka_g2x2)
+    template <bool UNIFORM = true, bool FIT = false>
     __device__ __forceinline__ void init(const DevParams<float> &P)
     {
-        K.init();
-        Q.init<UNIFORM>(P);
+        K.template init<FIT>();
+        Q.template init<UNIFORM, FIT>(P);
     }
     // (sin, cos) of a steering angle exactly as the FAST step computes it (for control tables
     // that carry them per entry)

@@ -695,6 +695,15 @@ class VehicleModel:
             *be.stream_args())
         return o0, o1
 
+    @staticmethod
+    def tire_fit(shape_factor):
+        """The fp32 step's fit for one wheel with Pacejka shape factor C (include/vdyn.h,
+        ``vdyn_tire_fit_f32``; host arithmetic, no device needed): ``(coef [9] float32, highest degree
+        first; validated: bool)`` with ``sin(C atan x) / x = c P(c)``, ``c = 1 / sqrt(1 + x^2)``."""
+        coef = np.zeros(9, dtype=np.float32)
+        rc = _lib.load().vdyn_tire_fit_f32(float(shape_factor), coef.ctypes.data_as(C.c_void_p))
+        return coef, rc == 0
+
     def synchronize(self, device=None):
         """Wait for the default stream of `device` (NumPy calls are already synchronous)."""
         d = self.device if device is None else device

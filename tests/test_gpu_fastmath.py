@@ -49,13 +49,21 @@ def test_scalar_forms(gpu_vm, dtype):
 def test_packed_forms_of_the_fp32_step(gpu_vm):
     vm = gpu_vm(1e-3)
     ev = lambda fn, x, c=0.0: [np.asarray(o, np.float64) for o in vm.fastmath_eval(fn, x.astype(np.float32), c)]
-    # sin(C atan(x)) in its cosine form: absolute accuracy (the reflected sine it replaced was relative)
-    x = np.concatenate([_grid(0.0, 4.0, 200001), _grid(1e-8, 1e7, 100000, log=True)]).astype(np.float32)
-    worst = 0.0
+    # the tire chain: sin(C atan x) = x c W_C(c), c = rsq(1 + x^2), with the handle's own fit of W_C -- every x, either sign
+    x = np.concatenate([[0.0], _grid(-4.0, 4.0, 200001), _grid(1e-8, 1e7, 100000, log=True, both=True)]).astype(np.float32)
+    xd = x.astype(np.float64)
+    worst = worst_g = 0.0
     for c in (1.5047, 0.25, 1.0, 1.3, 1.9, 2.0):
-        got = ev(5, x, c)[0]
-        worst = max(worst, np.abs(got - np.sin(c * np.arctan(x.astype(np.float64)))).max())
+        mu, g = ev(5, x, c)
+        worst = max(worst, np.abs(mu - np.sin(c * np.arctan(xd))).max())
+        small = np.abs(xd) <= np.sqrt(3.0)
+        gref = np.where(xd != 0, np.sin(c * np.arctan(xd)) / np.where(xd != 0, xd, 1.0), c)
+        worst_g = max(worst_g, (np.abs(g - gref) / np.abs(gref))[small].max())
+        assert abs(g[0] - c) <= 5e-7 * c                   # G(0) = C: quirk Q5 (s == 0) needs no branch
     assert worst <= 5e-7, f"sin(C atan x): {worst:.2e}"
+    assert worst_g <= 5e-7, f"sin(C atan x) / x, relative for x <= sqrt(3): {worst_g:.2e}"
+    with pytest.raises(Exception):
+        vm.fastmath_eval(5, x, 3.0)                        # no validated fit for this shape factor
     # unwrapped yaw: |x| <= 2^16
     x = np.concatenate([_grid(-50.0, 50.0, 200001), _grid(1.0, 65536.0, 100000, log=True, both=True)]).astype(np.float32)
     gs, gc = ev(6, x)
@@ -69,7 +77,7 @@ def test_packed_forms_of_the_fp32_step(gpu_vm):
     x = _grid(-np.pi / 4, np.pi / 4, 200001).astype(np.float32)
     gs, gc = ev(8, x)
     assert _rel(gs, np.sin(x.astype(np.float64)), 1e-300).max() <= 2.5e-7 and np.abs(gc - np.cos(x.astype(np.float64))).max() <= 2.0e-7
-    print(f"\n  packed: sin(C atan x) abs {worst:.2e}, yaw sincos abs {ey:.2e}")
+    print(f"\n  packed: sin(C atan x) abs {worst:.2e}, G relative {worst_g:.2e}, yaw sincos abs {ey:.2e}")
     with pytest.raises(Exception):
         vm.fastmath_eval(5, x.astype(np.float64))          # packed forms exist in fp32 only
 
