@@ -431,15 +431,20 @@ int vdyn_nonfinite_lanes_f32_host(VdynHandle *h, int32_t rows, int64_t n, const 
  * all four wheels pass and 0 <= C <= 2, B >= 0, and keep the atan -> sine chain otherwise -- or VDYN_ERR_ARG
  * (coef is still filled in). */
 int vdyn_tire_fit_f32(double C, float *coef);
+/* The same for the fp64 step: coef [19], degree 18, checked to 4e-15.  The fp64 kernels carry ONE set of
+ * coefficients: a handle uses the fit only if its four wheels share C (the reference's parameters do,
+ * vehicle_model.py:44-45). */
+int vdyn_tire_fit_f64(double C, double *coef);
 
 /* Device self-test of the bounded-range elementary functions the FAST step is built from
  * (csrc/vdyn_fastmath.hpp, csrc/vdyn_packed.hpp): evaluates function `fn` on x [n] (with the scalar
  * parameter `c` where one applies) -> out0 [n], out1 [n] (second result, or untouched).
  *   fn 0 atan_rcp(x, 1/x)          1 sin_0_pi(x)           2 sin_mid(x)        3 sincos_mid(x) -> (sin, cos)
  *      4 sincos_kernel(x) -> (sin, cos)        [scalar forms, fp32 and fp64]
+ *      5 the tire chain of the step (csrc/vdyn_packed.hpp, pacejka_g2x2; fp64: tire_force in
+ *        csrc/vdyn_device.hpp) with the fit of C = c, any x:
+ *        -> (sin(c atan x), sin(c atan x) / x); an error if that C has no validated fit
  *   fp32 only, the packed step's own forms:
- *      5 the tire chain of the step (csrc/vdyn_packed.hpp, pacejka_g2x2) with the fit of C = c, any x:
- *        -> (sin(c atan x), sin(c atan x) / x); VDYN_ERR_ARG if that C has no validated fit
  *      6 sincos of an unwrapped yaw -> (sin, cos)
  *      7 small stage rotation -> (sin, cos)     8 steering sincos kernel -> (sin, cos)
  * tests/test_gpu_fastmath.py holds each to its stated accuracy against float64 libm.                  */

@@ -80,6 +80,7 @@ for _s in ("f32", "f64"):
     SIGNATURES[f"vdyn_fastmath_eval_{_s}_dev"] = (_int, [_vp, _i32, _i64, _vp, _dbl, _vp, _vp, _vp])
     SIGNATURES[f"vdyn_fastmath_eval_{_s}_host"] = (_int, [_vp, _i32, _i64, _vp, _dbl, _vp, _vp])
 SIGNATURES["vdyn_tire_fit_f32"] = (_int, [_dbl, _vp])
+SIGNATURES["vdyn_tire_fit_f64"] = (_int, [_dbl, _vp])
 
 _gp = C.POINTER(VdynCtrlGains)
 for _s in ("f32", "f64"):

@@ -378,7 +378,7 @@ template <typename T>
 int fastmath_dev(VdynHandle *h, int32_t fn, int64_t n, const T *x, double c, T *out0, T *out1, void *stream)
 {
     if (!h) return VDYN_ERR_ARG;
-    if (fn < 0 || fn > (sizeof(T) == 4 ? 8 : 4) || n < 0) return h->fail(VDYN_ERR_ARG, "fastmath_eval: unknown function or n < 0");
+    if (fn < 0 || fn > (sizeof(T) == 4 ? 8 : 5) || n < 0) return h->fail(VDYN_ERR_ARG, "fastmath_eval: unknown function or n < 0");
     if (n == 0) return VDYN_OK;
     if (!x || !out0) return h->fail(VDYN_ERR_ARG, "fastmath_eval: null buffer");
     VDYN_HIP(h, hipSetDevice(h->device));
@@ -1185,6 +1185,11 @@ extern "C" int vdyn_tire_fit_f32(double C, float *coef)
 {
     if (coef == nullptr) return VDYN_ERR_ARG;
     return vdyn::tire_fit_coefficients(C, coef) ? VDYN_OK : VDYN_ERR_ARG;   // no handle: nothing to hang a message on
+}
+extern "C" int vdyn_tire_fit_f64(double C, double *coef)
+{
+    if (coef == nullptr) return VDYN_ERR_ARG;
+    return vdyn::tire_fit_coefficients64(C, coef) ? VDYN_OK : VDYN_ERR_ARG;
 }
 
 VDYN_DEFINE_ABI(f32, float)

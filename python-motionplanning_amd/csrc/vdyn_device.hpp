@@ -35,12 +35,22 @@ namespace vdyn {
 // only singularity at c = -1, so ONE polynomial of degree kTireFitDeg in c covers every slip from 0 to infinity
 // (c in (0, 1]) -- no argument reduction, no branch, no x > 1 case.  The coefficients depend on C, which belongs to
 // the handle: the host fits them when it builds DevParams (make_dev_params, vdyn_kernels.hip) and checks the fp32
-// Horner evaluation against double; W[i][wheel], highest degree first.  fp64 keeps the atan -> cosine chain.
+// Horner evaluation against double; W[i][wheel], highest degree first.
+// fp64 (the trimmed scalar step below and the wheel-parallel one): degree 18, and ONE set of coefficients -- the
+// four wheels must share C (true of the reference's parameters, vehicle_model.py:44-45); nineteen doubles per
+// wheel would not fit the scalar registers a wave-uniform constant lives in.  A handle that does not qualify
+// (different C per wheel, or a fit that fails its check) takes the general atan -> sine chain (lane_cs).
 constexpr int kTireFitDeg = 8;
-template <typename T> struct TireFit {};
+constexpr int kTireFitDeg64 = 18;
+template <typename T> struct TireFit;
 template <> struct TireFit<float> {
     float W[kTireFitDeg + 1][4];
 };
+template <> struct TireFit<double> {
+    double W[kTireFitDeg64 + 1];
+};
+__device__ __forceinline__ const double *tire_fit64(const TireFit<double> &f) { return f.W; }
+__device__ __forceinline__ const float *tire_fit64(const TireFit<float> &) { return nullptr; }
 
 template <typename T>
 struct DevParams : TireFit<T> {
@@ -177,7 +187,6 @@ struct StepInv {
     T Fz[4];         // normal loads from the PREVIOUS step's accelerations (:255-258, quirk Q3)
     T muFz[4];       // mu_max_i * Fz_i  (mu_max replaces Pacejka D, :232-235, quirk Q1)
     T tq[4];         // wheel torques (:226)
-    T phiB[4];       // (C - 1) pi/2: phase of the x > 1 branch of sin(C atan x) in its cosine form (trimmed step)
 };
 
 // K2 = true: the drive.py:142-143 pattern -- delta[1] == delta[0], rear angles exactly
@@ -211,8 +220,6 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
         M::sincos_steer(delta[2], &c.sd[2], &c.cd[2], ok);
         M::sincos_steer(delta[3], &c.sd[3], &c.cd[3], ok);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) c.phiB[i] = (P.C[i] - T(1)) * T(1.5707963267948966192313);
     // :255-258
     c.Fz[0] = P.Fz0F - P.DfzxL * ax_prev - P.DfzyF * ay_prev;
     c.Fz[1] = P.Fz0F - P.DfzxR * ax_prev + P.DfzyF * ay_prev;
@@ -230,7 +237,7 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
 //   :274-281 rotation, :284-293 slips (quirk Q4: signed vx for s_x, |vx| for s_y),
 //   :296-299 combined slip, :303-348 Pacejka + split, :351-373 forces.
 template <typename T, bool STEERED, bool SAFE, bool CS>
-__device__ __forceinline__ void tire_force(T B, T invB, T C, T phiB, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
+__device__ __forceinline__ void tire_force(T B, T invB, T C, const T *W, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
                                            T &fx, T &fy, T &fxt, T &fyt, T &s_out)
 {
     using M = Math<T, SAFE>;
@@ -242,16 +249,19 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, T phiB, T rw, T vxc
         vx = vxc;
         vy = vyc;
     }
-    if (M::kTrim && CS) {
-        // trimmed form (as vdyn_packed.hpp): slips pre-multiplied by B >= 0, so x = B s comes out of the
-        // rsq that normalises the slip, 1/x is that rsq, and B cancels in s_x mu / s; sin in its cosine form
+    if constexpr (M::kTrim && CS) {
+        // trimmed form (as vdyn_packed.hpp): slips pre-multiplied by B and
+        //   s_x mu / s = (B s_x) G(B s),  G(x) = sin(C atan x) / x = c W_C(c),  c = rsq(1 + x^2)
+        // with the handle's own polynomial W (TireFit above): no 1/s, no s, no case x > 1, and quirk Q5
+        // (s == 0) needs nothing -- G(0) = C is what the reference's fallback branch returns in the limit
         const T rvxB = M::rcp(vx) * B;
         const T sxb = fma_t(rw, w, -vx) * rvxB;
         const T syb = -vy * abs_t(rvxB);
-        const T x2 = sxb * sxb + syb * syb;
-        const T x2c = x2 > tiny_t(T(0)) ? x2 : tiny_t(T(0));      // quirk Q5, see below
-        const T rx = M::rsqrt(x2c);
-        const T gf = fm64::sin_c_atan_cs(C, phiB, x2c * rx, rx) * rx * muFz;
+        const T cc = M::rsqrt(fma_t(sxb, sxb, fma_t(syb, syb, T(1))));
+        T g = fma_t(W[0], cc, W[1]);
+#pragma unroll
+        for (int i = 2; i <= kTireFitDeg64; ++i) g = fma_t(g, cc, W[i]);
+        const T gf = g * (cc * muFz);
         fxt = sxb * gf;
         fyt = syb * gf;
         if (STEERED) {
@@ -261,7 +271,10 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, T phiB, T rw, T vxc
             fx = fxt;
             fy = fyt;
         }
-        s_out = x2 * rx * invB;
+        {   // the combined slip itself, diagnostics only (dead code elsewhere): |x| / B, exactly 0 at x = 0
+            const T x2 = fma_t(sxb, sxb, syb * syb);
+            s_out = x2 * M::rsqrt(x2 > tiny_t(T(0)) ? x2 : tiny_t(T(0))) * invB;
+        }
         return;
     }
     const T rvx = M::rcp(vx);
@@ -312,13 +325,13 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     const T vFy = V + P.a * wz, vRy = V - P.b * wz;
 
     T fx[4], fy[4], fxt[4], fyt[4], sl[4];
-    tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], c.phiB[0], P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0],
+    tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], tire_fit64(P), P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0],
                               c.muFz[0], fx[0], fy[0], fxt[0], fyt[0], sl[0]);
-    tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], c.phiB[1], P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1],
+    tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], tire_fit64(P), P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1],
                               c.muFz[1], fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-    tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], c.phiB[2], P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
+    tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], tire_fit64(P), P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
                              c.muFz[2], fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-    tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], c.phiB[3], P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
+    tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], tire_fit64(P), P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
                              c.muFz[3], fx[3], fy[3], fxt[3], fyt[3], sl[3]);
 
     // :376-385

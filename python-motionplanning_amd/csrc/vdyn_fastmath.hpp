@@ -203,53 +203,6 @@ __device__ __forceinline__ double sin_0_pi(double y)
     return fma(r * u, p, r);
 }
 
-// sin(C theta) for theta = atan(x), x >= 0, 0 <= C <= 2, as cos(C theta - pi/2): theta = p (x <= 1) or
-// pi/2 - p (x > 1) with p = atan(min(x, 1/x)), and cos is even, so the argument is z = C p - phi with
-// phi = pi/2 or (C - 1) pi/2 (`phi_big`, per wheel and step) -- no reflection, no second reduction.
-// cos(z) on |z| <= pi/2: degree 10 in z^2 (tools/fit_polys_f64.py style fit, 2.1e-16 absolute).
-__device__ __forceinline__ double sin_c_atan_cs(double C, double phi_big, double x, double inv_x)
-{
-    const bool big = x > 1.0;
-    const double t = big ? inv_x : x;
-    const double u = t * t;
-    double p = 5.4235777122049743556e-6;
-    p = fma(p, u, -0.000068150143017768600815);
-    p = fma(p, u, 0.00040788678988090017583);
-    p = fma(p, u, -0.0015537533402612332627);
-    p = fma(p, u, 0.0042551148264804944648);
-    p = fma(p, u, -0.0089974339942772711199);
-    p = fma(p, u, 0.015464694610323185545);
-    p = fma(p, u, -0.022566714208211488805);
-    p = fma(p, u, 0.029121244608854832768);
-    p = fma(p, u, -0.034556867496289890707);
-    p = fma(p, u, 0.039051162476945009974);
-    p = fma(p, u, -0.043181268997216635355);
-    p = fma(p, u, 0.047543887590470330271);
-    p = fma(p, u, -0.052616416091309294506);
-    p = fma(p, u, 0.058821133510041307054);
-    p = fma(p, u, -0.066666376799540371802);
-    p = fma(p, u, 0.076923050864584886996);
-    p = fma(p, u, -0.090909089238135856884);
-    p = fma(p, u, 0.11111111103899985381);
-    p = fma(p, u, -0.14285714285522452249);
-    p = fma(p, u, 0.19999999999997281691);
-    p = fma(p, u, -0.33333333333333317957);
-    p = fma(p * u, t, t);
-    const double z = fma(C, p, -(big ? phi_big : 1.570796326794896557998982));
-    const double w = z * z;
-    double q = 3.990954342789296286707e-19;
-    q = fma(q, w, -1.561222684593423174496e-16);
-    q = fma(q, w, 4.779454211708180433998e-14);
-    q = fma(q, w, -1.147074512175713550535e-11);
-    q = fma(q, w, 2.087675698157093318173e-9);
-    q = fma(q, w, -2.755731922393237511765e-7);
-    q = fma(q, w, 0.00002480158730158701802817);
-    q = fma(q, w, -0.001388888888888888801233);
-    q = fma(q, w, 0.04166666666666666665277);
-    q = fma(q, w, -0.4999999999999999999991);
-    return fma(q, w, 1.0);
-}
-
 // (sin d, cos d) of a stage's yaw increment, |d| <= kStageYawLimit64: Taylor to d^7 / d^6
 // (2.5e-18 relative / 2.3e-17 absolute at the limit).
 constexpr double kStageYawLimit64 = 0.03125;

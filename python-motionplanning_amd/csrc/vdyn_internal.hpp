@@ -53,6 +53,7 @@ template <typename T>
 hipError_t launch_nonfinite_lanes(int rows, int64_t n, const T *x, int *status, unsigned long long *count, hipStream_t st);
 // the handle's fp32 tire fit for one wheel (vdyn_kernels.hip, fp32 translation unit): coef [kTireFitDeg + 1]
 bool tire_fit_coefficients(double C, float *coef);
+bool tire_fit_coefficients64(double C, double *coef);   // [kTireFitDeg64 + 1]
 
 template <typename T>
 hipError_t launch_fastmath_eval(int fn, int64_t n, const T *x, double c, T *out0, T *out1, hipStream_t st);

@@ -380,7 +380,7 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
     const int64_t r = active ? (gid >> 2) : n - 1;
     const WheelLane<T> L = make_wheel_lane<T>(P, q);
     QuadEngine<T> qe;
-    qe.init(P, L);
+    qe.init(P, L, q);
 
     QuadState<T> s;
     s.U = state0[r];
@@ -1172,7 +1172,7 @@ template <> struct FmSel<double> {
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, TireFit<float> fit, T *__restrict__ out0,
+fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, TireFit<T> fit, T *__restrict__ out0,
                      T *__restrict__ out1)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1190,7 +1190,18 @@ fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, TireFit<fl
     case 3: F::sincos_mid(v, &a, &b); two = true; break;
     case 4: F::sincos_kernel(v, &a, &b); two = true; break;
     default:
-        if (sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 8) {
+            if (fn == 5) {
+                // the trimmed fp64 step's tire chain (tire_force in vdyn_device.hpp) with the fit of C = c
+                const T cc = Math<T, false>::rsqrt(fma_t(v, v, T(1)));
+                T g = fma_t(fit.W[0], cc, fit.W[1]);
+#pragma unroll
+                for (int j = 2; j <= kTireFitDeg64; ++j) g = fma_t(g, cc, fit.W[j]);
+                b = g * cc;
+                a = g * (cc * v);
+                two = true;
+            }
+        } else {
             const float vf = (float)v;
             if (fn == 5) {
                 // the FAST step's tire chain: x sin(C atan x) / x through pacejka_g2x2 with the fit of C = c
@@ -1225,62 +1236,66 @@ fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, TireFit<fl
 // ---------------------------------------------------------------- launchers ---------
 
 // ---- the handle's tire fit (TireFit in vdyn_device.hpp) ---------------------------------------
-// W_C(c) = sin(C acos c) / sqrt(1 - c^2) on c in [0, 1], in double.
-static double tire_w_exact(double C, double c)
+// W_C(c) = sin(C acos c) / sqrt(1 - c^2) on c in [0, 1], in long double (the reference the fp64 fit is held to).
+static long double tire_w_exact(long double C, long double c)
 {
-    const double th = std::acos(std::min(1.0, std::max(-1.0, c)));
-    if (th < 1e-4) return C * (1.0 + (1.0 - C * C) * th * th / 6.0);       // sin(C th) / sin(th), both expanded
-    return std::sin(C * th) / std::sin(th);
+    const long double th = acosl(std::min(1.0L, std::max(-1.0L, c)));
+    if (th < 1e-5L) return C * (1.0L + (1.0L - C * C) * th * th / 6.0L);   // sin(C th) / sin(th), both expanded
+    return sinl(C * th) / sinl(th);
 }
 
-// Degree-kTireFitDeg interpolant of W_C at the Chebyshev nodes of [0, 1] (within a small factor of the minimax
-// polynomial; what limits the result is the fp32 Horner evaluation, not the fit), as monomial coefficients in c,
-// highest degree first, rounded to float.  Then the check: the fp32 Horner value against double on 4097 points --
-// absolute error of mu / D = sin(C atan x) below 5e-7 everywhere, relative error of G = sin(C atan x) / x (the
-// cornering / longitudinal stiffness at small slip) below 5e-7 for x <= sqrt(3).  False if the check fails.
-static bool fit_tire_wheel(double C, float W[kTireFitDeg + 1])
+// Degree-DEG interpolant of W_C at the Chebyshev nodes of [0, 1] (within a small factor of the minimax
+// polynomial; what limits the result is the Horner evaluation in T, not the fit), as monomial coefficients in c,
+// highest degree first, rounded to T.  Then the check: the Horner value in T (one rounding per fma, as on the
+// device) against long double on 4097 points -- absolute error of mu / D = sin(C atan x) within `tol` everywhere,
+// relative error of G = sin(C atan x) / x (the cornering / longitudinal stiffness at small slip) within `tol`
+// for x <= sqrt(3).  False if the check fails.
+template <typename T, int DEG>
+static bool fit_tire_wheel(double C, T *W, double tol)
 {
-    constexpr int n = kTireFitDeg + 1;
-    const double pi = 3.14159265358979323846;
-    double f[n], a[n];
-    for (int k = 0; k < n; ++k) f[k] = tire_w_exact(C, 0.5 * (std::cos(pi * (2 * k + 1) / (2.0 * n)) + 1.0));
+    constexpr int n = DEG + 1;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double f[n], a[n];
+    for (int k = 0; k < n; ++k) f[k] = tire_w_exact(C, 0.5L * (cosl(pi * (2 * k + 1) / (2.0L * n)) + 1.0L));
     for (int j = 0; j < n; ++j) {
-        double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc += f[k] * std::cos(pi * j * (2 * k + 1) / (2.0 * n));
-        a[j] = acc * (j == 0 ? 1.0 : 2.0) / n;
+        long double acc = 0.0L;
+        for (int k = 0; k < n; ++k) acc += f[k] * cosl(pi * j * (2 * k + 1) / (2.0L * n));
+        a[j] = acc * (j == 0 ? 1.0L : 2.0L) / n;
     }
     // sum_j a_j T_j(2 c - 1) as a polynomial in c: T_0 = 1, T_1 = z, T_{j+1} = 2 z T_j - T_{j-1}, z = 2 c - 1
-    double t0[n] = {1.0}, t1[n] = {-1.0, 2.0}, m[n] = {0.0};
-    for (int i = 0; i < n; ++i) m[i] = a[0] * t0[i] + (n > 1 ? a[1] * t1[i] : 0.0);
+    long double t0[n] = {1.0L}, t1[n] = {-1.0L, 2.0L}, m[n];
+    for (int i = 0; i < n; ++i) m[i] = a[0] * t0[i] + a[1] * t1[i];
     for (int j = 2; j < n; ++j) {
-        double t2[n];
-        for (int i = 0; i < n; ++i) t2[i] = 2.0 * ((i > 0 ? 2.0 * t1[i - 1] : 0.0) - t1[i]) - t0[i];
+        long double t2[n];
+        for (int i = 0; i < n; ++i) t2[i] = 2.0L * ((i > 0 ? 2.0L * t1[i - 1] : 0.0L) - t1[i]) - t0[i];
         for (int i = 0; i < n; ++i) { m[i] += a[j] * t2[i]; t0[i] = t1[i]; t1[i] = t2[i]; }
     }
-    for (int i = 0; i < n; ++i) W[i] = (float)m[n - 1 - i];
+    for (int i = 0; i < n; ++i) W[i] = (T)m[n - 1 - i];
     if (!std::isfinite(C)) return false;
     for (int i = 0; i <= 4096; ++i) {
-        const float c = (float)i / 4096.0f;
-        float g = std::fmaf(W[0], c, W[1]);
-        for (int k = 2; k < n; ++k) g = std::fmaf(g, c, W[k]);
-        const double want = tire_w_exact(C, (double)c), err = std::fabs((double)g - want);
-        if (!(err * std::sqrt(std::max(0.0, 1.0 - (double)c * c)) <= 5e-7)) return false;
-        if (c >= 0.5f && !(err <= 5e-7 * std::max(std::fabs(want), 1e-30))) return false;
+        const T c = (T)i / (T)4096;
+        T g = std::fma(W[0], c, W[1]);
+        for (int k = 2; k < n; ++k) g = std::fma(g, c, W[k]);
+        const long double want = tire_w_exact(C, (long double)c), err = fabsl((long double)g - want);
+        if (!(err * sqrtl(std::max(0.0L, 1.0L - (long double)c * c)) <= tol)) return false;
+        if (c >= (T)0.5 && !(err <= tol * std::max(fabsl(want), 1e-300L))) return false;
     }
     return true;
 }
+constexpr double kTireFitTol32 = 5e-7, kTireFitTol64 = 4e-15;
 
 struct TireFitHost {
     double C[4];
     float W[kTireFitDeg + 1][4];
-    bool ok, filled;
+    double W64[kTireFitDeg64 + 1];
+    bool ok, ok64, filled;
 };
 
-// The fit of a handle's four shape factors; the last one computed is kept per thread (a launch per 0.2 ms must not
-// refit: the key is C alone, B does not enter W_C).
+// The fits of a handle's four shape factors; the last set computed is kept per thread (a launch per 0.2 ms must
+// not refit: the key is C alone, B does not enter W_C).
 static const TireFitHost &tire_fit(const VdynParams &p)
 {
-    static thread_local TireFitHost cache = {{0, 0, 0, 0}, {{0}}, false, false};
+    static thread_local TireFitHost cache = {{0, 0, 0, 0}, {{0}}, {0}, false, false, false};
     if (cache.filled && cache.C[0] == p.C[0] && cache.C[1] == p.C[1] && cache.C[2] == p.C[2] && cache.C[3] == p.C[3])
         return cache;
     cache.ok = true;
@@ -1293,10 +1308,13 @@ static const TireFitHost &tire_fit(const VdynParams &p)
             for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = cache.W[i][same];
             continue;
         }
-        const bool ok = fit_tire_wheel(p.C[w], col);
+        const bool ok = fit_tire_wheel<float, kTireFitDeg>(p.C[w], col, kTireFitTol32);
         cache.ok = cache.ok && ok;
         for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = col[i];
     }
+    // fp64: one set of coefficients, so the four wheels must share C
+    const bool same_c = p.C[0] == p.C[1] && p.C[0] == p.C[2] && p.C[0] == p.C[3];
+    cache.ok64 = fit_tire_wheel<double, kTireFitDeg64>(p.C[0], cache.W64, kTireFitTol64) && same_c;
     for (int w = 0; w < 4; ++w) cache.C[w] = p.C[w];
     cache.filled = true;
     return cache;
@@ -1306,9 +1324,10 @@ template <typename T>
 DevParams<T> make_dev_params(const VdynParams &p, const double *mu4)
 {
     DevParams<T> d;
-    if constexpr (std::is_same<T, float>::value) {
+    {
         const TireFitHost &f = tire_fit(p);
-        std::memcpy(d.W, f.W, sizeof(d.W));
+        if constexpr (std::is_same<T, float>::value) std::memcpy(d.W, f.W, sizeof(d.W));
+        else std::memcpy(d.W, f.W64, sizeof(d.W));
     }
     d.inv_m = (T)(1.0 / p.m);
     d.inv_Izz = (T)(1.0 / p.Izz);
@@ -1340,14 +1359,13 @@ static bool shape_factors_small(const VdynParams &p)
     return true;
 }
 
-// The CS flag of the lane-per-rollout kernels: shape factors in the short-form range and, in fp32 (whose FAST step
-// then runs the handle's fitted tire chain), a fit that passed its check.
+// The CS flag of the lane-per-rollout kernels (and of the fp64 wheel-parallel one): shape factors in the short-form
+// range and a fit -- the FAST step then runs the handle's fitted tire chain -- that passed its check.
 template <typename T>
 static bool lane_cs(const VdynParams &p)
 {
     if (!shape_factors_small(p)) return false;
-    if (std::is_same<T, float>::value) return tire_fit(p).ok;
-    return true;
+    return std::is_same<T, float>::value ? tire_fit(p).ok : tire_fit(p).ok64;
 }
 
 template <typename T, int K, int LAYOUT, bool DIAG, bool CS>
@@ -1455,7 +1473,7 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     // one step of the table must fit the LDS budget (k = 2 tables are staged 4 wide, see rollout_table_pre)
     if (layout == VDYN_CTRL_SHARED && (size_t)a.P * (a.k == 2 ? 4 : a.k) * sizeof(T) > (size_t)kLdsBudget) layout = 2;
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
-    const bool cs = lane_cs<T>(p), cs_quad = shape_factors_small(p);   // the wheel-parallel step keeps the atan chain
+    const bool cs = lane_cs<T>(p), cs_quad = cs;
     if (a.lanes_per_rollout == 4 && !diag) {
 #define VDYN_DISPATCH_Q(KK, LL)                                                        \
     if (a.k == KK && layout == LL)                                                     \
@@ -1518,15 +1536,21 @@ template <typename T>
 hipError_t launch_fastmath_eval(int fn, int64_t n, const T *x, double c, T *out0, T *out1, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    TireFit<float> fit;
+    TireFit<T> fit;
     std::memset(&fit, 0, sizeof(fit));
     if (fn == 5) {
         VdynParams p;
         std::memset(&p, 0, sizeof(p));
         for (int w = 0; w < 4; ++w) p.C[w] = c;
         const TireFitHost &f = tire_fit(p);
-        if (!f.ok) return hipErrorInvalidValue;            // no validated fit for this C: the step would not use it either
-        std::memcpy(fit.W, f.W, sizeof(fit.W));
+        // no validated fit for this C: the step would not use it either
+        if constexpr (std::is_same<T, float>::value) {
+            if (!f.ok) return hipErrorInvalidValue;
+            std::memcpy(fit.W, f.W, sizeof(fit.W));
+        } else {
+            if (!f.ok64) return hipErrorInvalidValue;
+            std::memcpy(fit.W, f.W64, sizeof(fit.W));
+        }
     }
     hipLaunchKernelGGL((fastmath_eval_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, fn, n, x,
                        (T)c, fit, out0, out1);
@@ -1747,7 +1771,8 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
 // compile in parallel and with the instruction-scheduling strategy that suits each (_build.py).
 #if !defined(VDYN_ONLY_F64)
 VDYN_INSTANTIATE(float)
-bool tire_fit_coefficients(double C, float *coef) { return fit_tire_wheel(C, coef); }
+bool tire_fit_coefficients(double C, float *coef) { return fit_tire_wheel<float, kTireFitDeg>(C, coef, kTireFitTol32); }
+bool tire_fit_coefficients64(double C, double *coef) { return fit_tire_wheel<double, kTireFitDeg64>(C, coef, kTireFitTol64); }
 #endif
 #if !defined(VDYN_ONLY_F32)
 VDYN_INSTANTIATE(double)

@@ -257,8 +257,11 @@ __device__ __forceinline__ void tire_force2x2(const PkConsts &K, const PkParams 
         VDYN_BOTH(q) s2[q] = fma2(sx[q], sx[q], s2[q]);                                           // 1 + (B s)^2
         pacejka_g2x2(Wq, s2, muFz, g);
         if (DIAG) {
+            // the combined slip itself, for the log only: |x| / B = x^2 rsq(x^2) / B, exactly 0 at x = 0 (quirk Q5)
+            const f2 tiny = splat(1e-30f);
             VDYN_BOTH(q) xs[q] = fma2(sx[q], sx[q], sy[q] * sy[q]);
-            VDYN_BOTH(q) s[q] = f2{__builtin_sqrtf(xs[q].x), __builtin_sqrtf(xs[q].y)} * invB[q];
+            VDYN_BOTH(q) rs[q] = f2{fm::rsq(::fmaxf(xs[q].x, tiny.x)), fm::rsq(::fmaxf(xs[q].y, tiny.y))};
+            VDYN_BOTH(q) s[q] = xs[q] * rs[q] * invB[q];
         }
     } else {
         // quirk Q5: s == 0 takes the fallback branch in the reference, whose value is what the regular

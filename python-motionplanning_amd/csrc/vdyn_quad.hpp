@@ -96,7 +96,7 @@ __device__ __forceinline__ void planar_deriv_quad(const DevParams<T> &P, const W
     const T vxc = fma_t(L.side, hTw, s.U);          // U -+ T wz / 2
     const T vyc = fma_t(L.lever, s.wz, s.V);        // V + a wz | V - b wz
     T fx, fy, fxt, fyt, slip;
-    tire_force<T, true, SAFE, CS>(L.B, L.invB, L.C, (L.C - T(1)) * T(1.5707963267948966192313), P.rw, vxc, vyc, s.w, cd, sd,
+    tire_force<T, true, SAFE, CS>(L.B, L.invB, L.C, tire_fit64(P), P.rw, vxc, vyc, s.w, cd, sd,
                                   muFz, fx, fy, fxt, fyt, slip);
     const T Sfx = quad_sum(fx);
     const T Sfy = quad_sum(fy);

@@ -4,11 +4,12 @@
 // quantities of the lane itself: corner velocity (vx, vy), slip (sx, sy), tire force (fx, fy),
 // (U, V), (x, y), (wz, yaw), (sin, cos), (axc, ayc).  Rotations and cross products are one or two
 // VOP3P instructions each (pk_cross / pk_hi_conj / pk_rot90 with the per-half sign bits), the
-// atan range split is the compare-free clamp indicator of vdyn_packed.hpp, and the integrator
-// state is three pairs + the lane's wheel speed.  457 -> 348 (round 1) -> ~285 VALU instructions per RK4 step with
-// the trims of the lane kernel (vdyn_packed.hpp: slips pre-multiplied by B, degree-7 atan, sin(C theta) in its cosine
-// form, force sums instead of accelerations, stage yaw increments as small rotations in the initial-yaw frame, mod-pi
-// sincos of yaw), all of it on a wave's critical path (these kernels run where the chip is mostly empty).
+// tire chain is the lane kernel's fitted one (pacejka_g2x2 in vdyn_packed.hpp, here scalar: one wheel, its own
+// nine coefficients), and the integrator state is three pairs + the lane's wheel speed.  457 -> 348 (round 1)
+// -> ~285 -> ~240 VALU instructions per RK4 step with the trims of the lane kernel (vdyn_packed.hpp: slips
+// pre-multiplied by B, fitted shape function, force sums instead of accelerations, stage yaw increments as small
+// rotations in the initial-yaw frame, mod-pi sincos of yaw), all of it on a wave's critical path (these kernels run
+// where the chip is mostly empty).
 //
 // Semantics: those of rk4_step_quad<float, false, true> (vdyn_quad.hpp).  Only the CS = true FAST
 // step is specialised; CS = false and the SAFE redo use the scalar code unchanged.
@@ -29,7 +30,7 @@ __device__ __forceinline__ f2 pk_rot90(f2 a, f2 b)        // (-a.y b.x, a.x b.x)
 
 template <typename T>
 struct QuadEngine {
-    __device__ __forceinline__ void init(const DevParams<T> &, const WheelLane<T> &) {}
+    __device__ __forceinline__ void init(const DevParams<T> &, const WheelLane<T> &, int) {}
     template <bool CS>
     __device__ __forceinline__ void advance(const DevParams<T> &P, const WheelLane<T> &L, QuadState<T> &s, T &ax,
                                             T &ay, T delta, T tq, T mu, T h) const
@@ -47,9 +48,9 @@ struct QuadEngine<float> {
     f2 inv_m2;
     float neg_rw_Jw, inv_Jw;             // -rw / Jw; 1 / Jw
     float mom_x, mom_y;                  // side T/2 / Izz, lever / Izz: yaw-moment arms of (fx, fy) (:378)
-    float kappa;                         // (2 - C) pi/2: phase of the x > 1 branch (sin_c_atan2x2)
+    float fw[kTireFitDeg + 1];           // this wheel's W_C(c), highest degree first (TireFit in vdyn_device.hpp)
 
-    __device__ __forceinline__ void init(const DevParams<float> &P, const WheelLane<float> &L)
+    __device__ __forceinline__ void init(const DevParams<float> &P, const WheelLane<float> &L, int q)
     {
         const float sks[3] = {-1.951163867e-04f, 8.332134224e-03f, -1.666665375e-01f};
         const float cks[3] = {2.443367339e-05f, -1.388732577e-03f, 4.166664556e-02f};
@@ -77,7 +78,8 @@ struct QuadEngine<float> {
         inv_m2 = f2{im, im};
         inv_Jw = iJ;
         neg_rw_Jw = -r_w * iJ;
-        kappa = (2.0f - L.C) * 1.57079637050628662109375f;
+#pragma unroll
+        for (int i = 0; i <= kTireFitDeg; ++i) fw[i] = q == 0 ? P.W[i][0] : q == 1 ? P.W[i][1] : q == 2 ? P.W[i][2] : P.W[i][3];
     }
 
     __device__ __forceinline__ f2 sincos_k(float r) const
@@ -126,32 +128,15 @@ struct QuadEngine<float> {
         const f2 wz2 = f2{s.wy.x, s.wy.x};
         const f2 vv = fma2(lv, wz2, s.uv);                                // corner velocity, chassis frame
         const f2 tv = fma2(vv, f2{dsc.y, dsc.y}, pk_cross(vv, dsc));      // :274-281 (vx, vy), tire frame
-        const float rvxB = fm::rcp(tv.x) * L.B;                           // B / vx (B >= 0: CS)
+        const float rvxB = fm::rcp(tv.x) * L.B;                           // B / vx
         const float sx = ::fmaf(P.rw, s.w, -tv.x) * rvxB;                 // B s_x   (:284-287)
         const float sy = -tv.y * ::fabsf(rvxB);                           // B s_y   (:290-293, quirk Q4)
-        const float x2 = ::fmaf(sx, sx, ::fmaf(sy, sy, 1e-30f));          // (B s)^2 (:296-299), quirk Q5 (see tire_force2x2)
-        const float rx = fm::rsq(x2);                                     // 1 / x
-        const float xs = x2 * rx;                                         // x = B s
-        // sin(C atan(x)), x >= 0, in its cosine form: cos(C p - phi), p = atan(min(x, 1/x)), phi = pi/2 - [x > 1] kappa
-        const float t = ::fminf(xs, rx);
-        const float ind = __builtin_amdgcn_fmed3f(::fmaf(xs, 0x1p100f, -0x1p100f), 0.0f, 1.0f);
-        const float u = t * t;
-        float p = -4.729942884e-03f;
-        p = ::fmaf(p, u, 2.439327165e-02f);
-        p = ::fmaf(p, u, -5.969851837e-02f);
-        p = ::fmaf(p, u, 9.930104017e-02f);
-        p = ::fmaf(p, u, -1.402552277e-01f);
-        p = ::fmaf(p, u, 1.997082233e-01f);
-        p = ::fmaf(p, u, -3.333206475e-01f);
-        p = ::fmaf(p, u, 9.999998808e-01f);
-        p = p * t;
-        const float z = ::fmaf(L.C, p, -::fmaf(ind, -kappa, 1.57079637050628662109375f));
-        const float w = z * z;
-        float q = ::fmaf(2.312937249e-05f, w, -1.385257230e-03f);
-        q = ::fmaf(q, w, 4.166342318e-02f);
-        q = ::fmaf(q, w, -4.999989867e-01f);
-        q = ::fmaf(q, w, 9.999999404e-01f);
-        const float g = q * rx * muFz;                                    // mu / s times Fz over B (B cancels with the scaled slips)
+        // G(B s) = sin(C atan x) / x = c W_C(c), c = rsq(1 + x^2) (:296-348; quirk Q5 needs no case, see pacejka_g2x2)
+        const float cc = fm::rsq(::fmaf(sx, sx, ::fmaf(sy, sy, 1.0f)));
+        float p = ::fmaf(fw[0], cc, fw[1]);
+#pragma unroll
+        for (int i = 2; i <= kTireFitDeg; ++i) p = ::fmaf(p, cc, fw[i]);
+        const float g = p * (cc * muFz);                                  // mu / s times Fz over B (B cancels with the scaled slips)
         const f2 ft = f2{sx, sy} * f2{g, g};                              // :351-360 (fxt, fyt)
         const f2 fc = fma2(ft, f2{dsc.y, dsc.y}, pk_rot90(ft, dsc));      // :363-373 (fx, fy), chassis frame
         const float Sfx = quad_sum(fc.x), Sfy = quad_sum(fc.y);

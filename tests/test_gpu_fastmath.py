@@ -79,7 +79,23 @@ def test_packed_forms_of_the_fp32_step(gpu_vm):
     assert _rel(gs, np.sin(x.astype(np.float64)), 1e-300).max() <= 2.5e-7 and np.abs(gc - np.cos(x.astype(np.float64))).max() <= 2.0e-7
     print(f"\n  packed: sin(C atan x) abs {worst:.2e}, G relative {worst_g:.2e}, yaw sincos abs {ey:.2e}")
     with pytest.raises(Exception):
-        vm.fastmath_eval(5, x.astype(np.float64))          # packed forms exist in fp32 only
+        vm.fastmath_eval(6, x.astype(np.float64))          # packed forms exist in fp32 only
+
+
+def test_fitted_tire_chain_fp64(gpu_vm):
+    """fn 5 in fp64: the trimmed scalar step's chain, c = rsq(1 + x^2), degree-18 Horner with the fit of C."""
+    vm = gpu_vm(1e-3)
+    x = np.concatenate([[0.0], _grid(-4.0, 4.0, 200001), _grid(1e-8, 1e7, 100000, log=True, both=True)])
+    xl = x.astype(np.longdouble)
+    worst = worst_g = 0.0
+    for c in (1.5047, 0.25, 1.0, 1.3, 1.9, 2.0):
+        mu, g = [np.asarray(o, np.float64).astype(np.longdouble) for o in vm.fastmath_eval(5, x, c)]
+        worst = max(worst, float(np.abs(mu - np.sin(c * np.arctan(xl))).max()))
+        small = np.abs(xl) <= np.sqrt(3.0)
+        gref = np.where(xl != 0, np.sin(c * np.arctan(xl)) / np.where(xl != 0, xl, 1.0), c)
+        worst_g = max(worst_g, float((np.abs(g - gref) / np.abs(gref))[small].max()))
+    assert worst <= 4e-15 and worst_g <= 4e-15, f"{worst:.2e} {worst_g:.2e}"
+    print(f"\n  fp64 fitted chain: sin(C atan x) abs {worst:.2e}, G relative {worst_g:.2e}")
 
 
 def test_nonfinite_lanes_status(gpu_vm, workloads):

@@ -42,3 +42,21 @@ def test_integer_shape_factors_are_chebyshev_polynomials(pkg):
 def test_fit_that_fails_its_check_is_reported(pkg, C):
     _, ok = pkg.VehicleModel.tire_fit(C)
     assert not ok          # such a handle keeps the atan -> sine chain (lane_cs in csrc/vdyn_kernels.hip)
+
+
+@pytest.mark.parametrize("C", [1.5047, 0.0, 0.5, 1.0, 1.3, 1.9, 2.0])
+def test_fp64_fit(pkg, C):
+    """Degree 18, 19 coefficients, one set per handle (the four wheels must share C): checked to 4e-15 by the
+    library, here against long-double NumPy with a plain (unfused) Horner loop."""
+    coef, ok = pkg.VehicleModel.tire_fit(C, np.float64)
+    assert ok and coef.dtype == np.float64 and coef.shape == (19,)
+    x = np.concatenate([[0.0], np.linspace(0.0, 4.0, 100001), np.geomspace(1e-8, 1e8, 50001)]).astype(np.longdouble)
+    c = (1.0 / np.sqrt(1.0 + x * x)).astype(np.float64)
+    g = np.full_like(c, coef[0])
+    for a in coef[1:]:
+        g = g * c + a
+    G = (g * c).astype(np.longdouble)
+    want = np.where(x > 0, np.sin(C * np.arctan(x)) / np.where(x > 0, x, 1.0), C)
+    assert np.max(np.abs(G - want) * x) <= 4e-15
+    small = x <= np.sqrt(3.0)
+    assert np.max((np.abs(G - want) / np.maximum(np.abs(want), 1e-300))[small]) <= 4e-15
