@@ -1006,6 +1006,52 @@ def test_general_tire_shape_path(gpu_vm, pkg, oracle, workloads):
         assert e32 <= max(3e-5, 3 * floor), (e32, floor)
 
 
+def test_fitted_tire_chain_across_slip_regimes(gpu_vm, pkg, oracle, workloads):
+    """The FAST step's tire chain is one polynomial in c = 1 / sqrt(1 + (B s)^2) for every slip (the handle's fit,
+    include/vdyn.h vdyn_tire_fit_*): rollouts that sit at the ends of that range -- locked and spinning wheels
+    (B s ~ 20), sideways and reversing vehicles (quirk Q4's |vx|), exactly zero slip (quirk Q5), hard steering --
+    against the oracle, fp64 and fp32, lane-per-rollout and wheel-parallel kernels; then tire sets with a different
+    shape factor per wheel (fp32: four fits; fp64: one set of coefficients, so such a handle takes the general
+    chain) and at the ends of the fitted range (C = 2 exactly, C near 0)."""
+    rw = 0.308309813617345
+    rows = []
+    for U in (8.0, 25.0):
+        base = np.zeros(12)
+        base[0] = U
+        base[3:7] = U / rw
+        for name, edit in (("zero_slip", lambda s: s),
+                           ("locked", lambda s: s.__setitem__(slice(3, 7), 0.0)),
+                           ("front_locked", lambda s: s.__setitem__(slice(3, 5), 0.0)),
+                           ("spinning", lambda s: s.__setitem__(slice(3, 7), 3.0 * U / rw)),
+                           ("sideways", lambda s: s.__setitem__(1, 0.9 * U)),
+                           ("yawing", lambda s: s.__setitem__(2, 1.5)),
+                           ("reverse", lambda s: (s.__setitem__(0, -U), s.__setitem__(slice(3, 7), -U / rw))),
+                           ("reverse_sideways", lambda s: (s.__setitem__(0, -U), s.__setitem__(1, 0.3 * U),
+                                                           s.__setitem__(slice(3, 7), -U / rw)))):
+            st = base.copy()
+            edit(st)
+            rows.append(st)
+    s0 = np.array(rows).T                                               # [12][16]
+    n, H, dt = s0.shape[1], 40, 1e-3
+    ctrl = np.zeros((H, 2, n))
+    ctrl[:, 0, :] = np.linspace(-0.5, 0.5, n)[None, :]                  # +- 29 deg, constant
+    ctrl[:, 1, :] = np.where(np.arange(n) % 2 == 0, 300.0, -800.0)[None, :]
+    VP = pkg.VehicleParameters
+    per_wheel = VP(CFL=1.2)
+    per_wheel.CFR, per_wheel.CRL, per_wheel.CRR = 1.35, 1.8, 1.95
+    ends = VP(CFL=2.0)
+    ends.CFR, ends.CRL, ends.CRR = 2.0, 0.05, 0.05
+    for veh in (VP(), per_wheel, ends):
+        want = oracle.rollout(oracle.params_from(veh), s0, ctrl, dt)
+        o32 = oracle.rollout(oracle.params_from(veh), s0.astype(np.float32), ctrl.astype(np.float32), dt)
+        floor = (np.abs(o32 - want) / np.abs(want).max(axis=1, keepdims=True)).max()
+        for lanes in (1, 4):
+            vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, params=veh, device=0, lanes_per_rollout=lanes)
+            assert parity(vm.rollout(s0, ctrl), want, F64_TOL, "fp64 slip regimes") <= 1e-9
+            e32 = parity(vm.rollout(s0.astype(np.float32), ctrl.astype(np.float32)), want, F32_TOL, "fp32 slip regimes")
+            assert e32 <= max(3e-5, 3 * floor), (lanes, e32, floor)
+
+
 def test_rollout_fuzz_shapes_layouts_kernels(pkg, oracle, workloads):
     """48 seeded combinations of batch size (1..3000, ragged against the 64-lane wave and the
     256-thread workgroup), horizon (0..40), control layout (per-rollout / shared with 1..40 paths),
