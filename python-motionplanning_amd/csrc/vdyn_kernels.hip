@@ -1244,12 +1244,19 @@ static long double tire_w_exact(long double C, long double c)
     return sinl(C * th) / sinl(th);
 }
 
+// One device fma on the host: fp32 through double (the product of two floats is exact there and the sum is rounded
+// once more to float -- the same value as a fused fma except in double-rounding ties far below the tolerances
+// checked here; glibc's software fmaf costs microseconds per call), fp64 through std::fma.
+static inline float fma_as_device(float a, float b, float c) { return (float)((double)a * (double)b + (double)c); }
+static inline double fma_as_device(double a, double b, double c) { return std::fma(a, b, c); }
+
 // Degree-DEG interpolant of W_C at the Chebyshev nodes of [0, 1] (within a small factor of the minimax
 // polynomial; what limits the result is the Horner evaluation in T, not the fit), as monomial coefficients in c,
 // highest degree first, rounded to T.  Then the check: the Horner value in T (one rounding per fma, as on the
-// device) against long double on 4097 points -- absolute error of mu / D = sin(C atan x) within `tol` everywhere,
+// device) against long double on 1025 points -- absolute error of mu / D = sin(C atan x) within `tol` everywhere,
 // relative error of G = sin(C atan x) / x (the cornering / longitudinal stiffness at small slip) within `tol`
-// for x <= sqrt(3).  False if the check fails.
+// for x <= sqrt(3).  False if the check fails.  ~0.1 ms (fp32) / 0.4 ms (fp64) per shape factor, once per thread
+// and C (tire_fit below keeps the results).
 template <typename T, int DEG>
 static bool fit_tire_wheel(double C, T *W, double tol)
 {
@@ -1272,10 +1279,11 @@ static bool fit_tire_wheel(double C, T *W, double tol)
     }
     for (int i = 0; i < n; ++i) W[i] = (T)m[n - 1 - i];
     if (!std::isfinite(C)) return false;
-    for (int i = 0; i <= 4096; ++i) {
-        const T c = (T)i / (T)4096;
-        T g = std::fma(W[0], c, W[1]);
-        for (int k = 2; k < n; ++k) g = std::fma(g, c, W[k]);
+    constexpr int kGrid = 1024;
+    for (int i = 0; i <= kGrid; ++i) {
+        const T c = (T)i / (T)kGrid;
+        T g = fma_as_device(W[0], c, W[1]);
+        for (int k = 2; k < n; ++k) g = fma_as_device(g, c, W[k]);
         const long double want = tire_w_exact(C, (long double)c), err = fabsl((long double)g - want);
         if (!(err * sqrtl(std::max(0.0L, 1.0L - (long double)c * c)) <= tol)) return false;
         if (c >= (T)0.5 && !(err <= tol * std::max(fabsl(want), 1e-300L))) return false;
@@ -1284,6 +1292,13 @@ static bool fit_tire_wheel(double C, T *W, double tol)
 }
 constexpr double kTireFitTol32 = 5e-7, kTireFitTol64 = 4e-15;
 
+// Both fits of one shape factor.
+struct TireFitC {
+    double C;
+    float W[kTireFitDeg + 1];
+    double W64[kTireFitDeg64 + 1];
+    bool ok, ok64;
+};
 struct TireFitHost {
     double C[4];
     float W[kTireFitDeg + 1][4];
@@ -1291,31 +1306,42 @@ struct TireFitHost {
     bool ok, ok64, filled;
 };
 
-// The fits of a handle's four shape factors; the last set computed is kept per thread (a launch per 0.2 ms must
-// not refit: the key is C alone, B does not enter W_C).
+// The fits of a handle's four shape factors.  Kept per thread: the handle's assembled set (a launch per 0.15 ms
+// must not refit -- four compares when C has not changed) and the last sixteen shape factors seen (a fleet table
+// of 256 classes is rebuilt per launch).  The key is C alone: B does not enter W_C.
+static const TireFitC &tire_fit_c(double C)
+{
+    constexpr int kSlots = 16;
+    static thread_local TireFitC slots[kSlots];
+    static thread_local int used = 0, next = 0;
+    for (int i = 0; i < used; ++i)
+        if (std::memcmp(&slots[i].C, &C, sizeof(C)) == 0) return slots[i];     // bitwise: NaN finds itself
+    TireFitC &e = slots[next];
+    next = (next + 1) % kSlots;
+    used = std::min(used + 1, kSlots);
+    e.C = C;
+    e.ok = fit_tire_wheel<float, kTireFitDeg>(C, e.W, kTireFitTol32);
+    e.ok64 = fit_tire_wheel<double, kTireFitDeg64>(C, e.W64, kTireFitTol64);
+    return e;
+}
+
 static const TireFitHost &tire_fit(const VdynParams &p)
 {
     static thread_local TireFitHost cache = {{0, 0, 0, 0}, {{0}}, {0}, false, false, false};
-    if (cache.filled && cache.C[0] == p.C[0] && cache.C[1] == p.C[1] && cache.C[2] == p.C[2] && cache.C[3] == p.C[3])
-        return cache;
+    if (cache.filled && std::memcmp(cache.C, p.C, sizeof(cache.C)) == 0) return cache;
     cache.ok = true;
     for (int w = 0; w < 4; ++w) {
-        float col[kTireFitDeg + 1];
-        int same = -1;
-        for (int v = 0; v < w; ++v)
-            if (p.C[v] == p.C[w]) same = v;
-        if (same >= 0) {
-            for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = cache.W[i][same];
-            continue;
+        const TireFitC e = tire_fit_c(p.C[w]);        // by value: a later lookup may recycle the slot
+        cache.ok = cache.ok && e.ok;
+        for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = e.W[i];
+        if (w == 0) {
+            std::memcpy(cache.W64, e.W64, sizeof(cache.W64));
+            cache.ok64 = e.ok64;
         }
-        const bool ok = fit_tire_wheel<float, kTireFitDeg>(p.C[w], col, kTireFitTol32);
-        cache.ok = cache.ok && ok;
-        for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = col[i];
     }
     // fp64: one set of coefficients, so the four wheels must share C
-    const bool same_c = p.C[0] == p.C[1] && p.C[0] == p.C[2] && p.C[0] == p.C[3];
-    cache.ok64 = fit_tire_wheel<double, kTireFitDeg64>(p.C[0], cache.W64, kTireFitTol64) && same_c;
-    for (int w = 0; w < 4; ++w) cache.C[w] = p.C[w];
+    cache.ok64 = cache.ok64 && p.C[0] == p.C[1] && p.C[0] == p.C[2] && p.C[0] == p.C[3];
+    std::memcpy(cache.C, p.C, sizeof(cache.C));
     cache.filled = true;
     return cache;
 }
