@@ -13,7 +13,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra"
 
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
+# the trace pass runs bench.py's default K = 200 / W = 20, so that the traced average is taken over the same
+# warmed-up launches bench.py times; the counter passes need only a few launches
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra > "$OUT/kt.log" 2>&1
 echo "kernel-trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc FETCH_SIZE done"
