@@ -1056,10 +1056,19 @@ def test_fitted_tire_chain_across_slip_regimes(gpu_vm, pkg, oracle, workloads):
 def test_rollout_fuzz_shapes_layouts_kernels(pkg, oracle, workloads):
     """48 seeded combinations of batch size (1..3000, ragged against the 64-lane wave and the
     256-thread workgroup), horizon (0..40), control layout (per-rollout / shared with 1..40 paths),
-    k (2 / 12), precision and kernel (lane / wheel-parallel), each against the oracle."""
+    k (2 / 12), precision, kernel (lane / wheel-parallel) and tire set (the reference's; one random B, C for all
+    wheels; random B, C per wheel -- every one fitted on the host before the launch), each against the oracle."""
     rng = np.random.default_rng(2024)
-    p = oracle.default_params()
+    trng = np.random.default_rng(77)
     for case in range(48):
+        veh = pkg.VehicleParameters()
+        if case % 3 == 1:
+            veh = pkg.VehicleParameters(BFL=float(trng.uniform(12, 28)), CFL=float(trng.uniform(0.8, 2.0)))
+        elif case % 3 == 2:
+            for w in ("FL", "FR", "RL", "RR"):
+                setattr(veh, "B" + w, float(trng.uniform(12, 28)))
+                setattr(veh, "C" + w, float(trng.uniform(0.8, 2.0)))
+        p = oracle.params_from(veh)
         n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 3000))]))
         H = int(rng.choice([0, 1, 2, int(rng.integers(3, 41))]))
         k = int(rng.choice([2, 12]))
@@ -1079,7 +1088,7 @@ def test_rollout_fuzz_shapes_layouts_kernels(pkg, oracle, workloads):
         else:
             c = np.concatenate([rng.uniform(-0.3, 0.3, (H, 2, nrow)), rng.uniform(-0.05, 0.05, (H, 2, nrow)),
                                 rng.uniform(-200, 400, (H, 4, nrow)), rng.uniform(0.6, 1.0, (H, 4, nrow))], axis=1)
-        vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, lanes_per_rollout=lanes)
+        vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, params=veh, lanes_per_rollout=lanes)
         if shared:
             pid = rng.integers(0, P, n).astype(np.int32)
             tab = np.ascontiguousarray(np.transpose(c, (2, 0, 1)))            # [P][H][k]
