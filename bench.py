@@ -479,6 +479,18 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     vmq.rollout(s2d, c2d)
     t = timed_launches(lambda: vmq.rollout(s2d, c2d), 5, torch)
     ex["config2_4096x200_f64_wheel_parallel"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
+    # the same launch with the steering table scaled by 8 (+-27 deg) and every fourth ego's wheels locked: tires
+    # from zero slip to far past the friction peak (B s up to ~20).  The step has no data-dependent path -- the
+    # fitted shape function covers every slip with one polynomial -- so this must cost what the headline costs.
+    tab_hi = torch.from_numpy(tab).to(dev).clone()
+    tab_hi[:, :, 0] *= 8.0
+    s_hi = s0.clone()
+    s_hi[3:7, ::28] = 0.0
+    vm.rollout(s_hi, tab_hi, path_id=pid)
+    t = timed_launches(lambda: vm.rollout(s_hi, tab_hi, path_id=pid), 5, torch)
+    ex["high_slip_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3,
+                                     "finite": bool(torch.isfinite(vm.rollout(s_hi, tab_hi, path_id=pid)).all())}
+    del tab_hi, s_hi
     s8 = s0[:, :8192].contiguous()
     p8 = pid[:8192].contiguous()
     tab8 = torch.from_numpy(tab).to(dev)
