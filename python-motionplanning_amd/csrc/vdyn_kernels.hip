@@ -108,6 +108,12 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
 
 // TRAJ: the launch writes trajectory rows.  A separate instance, because the test "is this a trajectory step" is
 // a (taken) branch per step on the normal path otherwise, and a lone wave pays tens of cycles for each.
+// After the fetch of the NEXT step's controls: no instruction may be scheduled across.  Left alone, the scheduler
+// sinks the load to ~25 instructions before its use at the end of the step it was meant to hide behind (an LDS read
+// takes longer than that for a lone wave); pinned at the top, the step ends on `s_waitcnt lgkmcnt(1)` for a load
+// issued a whole step earlier.  A/B on one box, two runs each: headline 0.1540 -> 0.1534 ms, per-rollout controls
+// (global loads) 0.1683 -> 0.1633 ms, configs[1] fp64 0.5235 -> 0.4927 ms; MPC and the closed loop unchanged.
+#define VDYN_FETCH_FENCE __builtin_amdgcn_sched_barrier(0);
 template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
@@ -166,12 +172,16 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             Ctrl<T, K> c2;
             for (; tc + 3 < tc_n; tc += 4) {
                 fetch(c2, tc + 1);
+                VDYN_FETCH_FENCE
                 eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
                 fetch(c, tc + 2);
+                VDYN_FETCH_FENCE
                 eng.template advance_state<K == 2, CS, PRE>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
                 fetch(c2, tc + 3);
+                VDYN_FETCH_FENCE
                 eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
                 fetch(c, min(tc + 4, tc_n - 1));
+                VDYN_FETCH_FENCE
                 eng.template advance_state<K == 2, CS, PRE>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             }
         }
@@ -540,9 +550,11 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         Ctrl<T, 2> c2;
         for (; t + 1 < H; t += 2) {            // two steps per trip, control sets ping-pong (see rollout_kernel)
             c2.set_pre(P, cand4 + ((int64_t)(t + 1) * C + c) * 4);
+            VDYN_FETCH_FENCE
             eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
             cc.set_pre(P, cand4 + ((int64_t)min(t + 2, H - 1) * C + c) * 4);
+            VDYN_FETCH_FENCE
             eng.template advance_state<true, CS, 1>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             dsum += c2.delta[0] * c2.delta[0];
         }
