@@ -375,7 +375,9 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
 
 // Wheel-parallel rollout (vdyn_quad.hpp): four adjacent lanes per rollout, 64 rollouts per
 // 256-thread workgroup.  Same interface as rollout_kernel minus the diagnostics.
-template <typename T, int K, int LAYOUT, bool CS>
+// TRAJ: the launch writes trajectory rows (an instance of its own, as for rollout_kernel: the test alone is a taken
+// branch per step otherwise).
+template <typename T, int K, int LAYOUT, bool CS, bool TRAJ>
 __global__ void __launch_bounds__(kBlock)
 rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                     const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
@@ -413,26 +415,36 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
             stage_control_table<T, K>(tab, ctrl, Pn, H, t0, tc_n);
             __syncthreads();
         }
-        for (int tc = 0; tc < tc_n; ++tc) {
+        // this lane's controls of step tc; step tc + 1's are fetched before step tc is integrated (see rollout_kernel)
+        struct QC { T delta, tq, mu; };
+        auto fetch = [&](int tc) __attribute__((always_inline)) {
             const int t = t0 + tc;
             const T *c;
             int64_t stride;
             if (LAYOUT == 0) { c = ctrl + ((int64_t)t * K) * n + r; stride = n; }
             else if (LAYOUT == 1) { c = tab + (int64_t)tc * K * Pn + pid; stride = Pn; }
             else { c = ctrl + ((int64_t)pid * H + t) * K; stride = 1; }
-            T delta, tq, mu;
+            QC o;
             if (K == 2) {
-                delta = L.front ? c[0] : T(0);          // drive.py:143: [d, d, 0, 0]
-                tq = c[stride];
-                mu = mu_k2;
+                o.delta = L.front ? c[0] : T(0);          // drive.py:143: [d, d, 0, 0]
+                o.tq = c[stride];
+                o.mu = mu_k2;
             } else {
-                delta = c[(int64_t)q * stride];
-                tq = c[(int64_t)(4 + q) * stride];
-                mu = c[(int64_t)(8 + q) * stride];
+                o.delta = c[(int64_t)q * stride];
+                o.tq = c[(int64_t)(4 + q) * stride];
+                o.mu = c[(int64_t)(8 + q) * stride];
             }
-            qe.template advance<CS>(P, L, s, ax, ay, delta, tq, mu, h);
+            return o;
+        };
+        QC cur = fetch(0);
+        for (int tc = 0; tc < tc_n; ++tc) {
+            const int t = t0 + tc;
+            const QC nxt = fetch(min(tc + 1, tc_n - 1));
+            VDYN_FETCH_FENCE
+            qe.template advance<CS>(P, L, s, ax, ay, cur.delta, cur.tq, cur.mu, h);
+            cur = nxt;
 
-            if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
+            if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
                 T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
                 row[(int64_t)(3 + q) * n] = s.w;
                 if (q == 0) {
@@ -1497,9 +1509,14 @@ static hipError_t launch_rollout_quad_impl(const VdynParams &p, const RolloutArg
         chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
         lds = (size_t)chunk * per_step;
     }
-    hipLaunchKernelGGL((rollout_quad_kernel<T, K, LAYOUT, CS>), dim3(grid), dim3(kBlock), lds, st, P, a.n, a.H,
-                       a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
-                       a.traj_stride > 0 ? a.traj_stride : 1);
+    if (a.traj != nullptr)
+        hipLaunchKernelGGL((rollout_quad_kernel<T, K, LAYOUT, CS, true>), dim3(grid), dim3(kBlock), lds, st, P, a.n, a.H,
+                           a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                           a.traj_stride > 0 ? a.traj_stride : 1);
+    else
+        hipLaunchKernelGGL((rollout_quad_kernel<T, K, LAYOUT, CS, false>), dim3(grid), dim3(kBlock), lds, st, P, a.n, a.H,
+                           a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                           a.traj_stride > 0 ? a.traj_stride : 1);
     return hipGetLastError();
 }
 
