@@ -63,6 +63,18 @@ struct DevParams : TireFit<T> {
     T mu[4];                    // mu_max used by k = 2 controls (drive.py:142: [1,1,1,1])
 };
 
+// fp64 kernels: move the nineteen fit coefficients from the scalar to the vector registers once, at the top of the
+// kernel.  As wave-uniform kernel arguments they sit in SGPRs, and together with the other constants of the step
+// they overflow the scalar file: the compiler then spills SGPRs into VGPR lanes and reads them back one
+// `v_readlane_b32` at a time (105 per RK4 step before this, 9 % of the instruction stream).  (fp32: the packed
+// step pins its own pairs, PkParams::init.)
+__device__ __forceinline__ void pin_tire_fit(DevParams<double> &P)
+{
+#pragma unroll
+    for (int i = 0; i <= kTireFitDeg64; ++i) asm volatile("" : "+v"(P.W[i]));
+}
+__device__ __forceinline__ void pin_tire_fit(DevParams<float> &) {}
+
 // ---- scalar math, by type and by path ------------------------------------------------
 template <typename T, bool SAFE> struct Math;
 

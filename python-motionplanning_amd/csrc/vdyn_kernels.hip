@@ -121,6 +121,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                T *__restrict__ terminal, T *__restrict__ traj, int traj_stride,
                T *__restrict__ state_dot_out, T *__restrict__ outputs_out)
 {
+    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *tab = reinterpret_cast<T *>(smem_raw);
 
@@ -243,6 +244,7 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
                       T wheelbase, T tan_max, T torque, T h, T *__restrict__ terminal, T *__restrict__ traj,
                       int traj_stride)
 {
+    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = gid < n;
     const int64_t r = active ? gid : n - 1;
@@ -383,6 +385,7 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
                     const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
                     T *__restrict__ terminal, T *__restrict__ traj, int traj_stride)
 {
+    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *tab = reinterpret_cast<T *>(smem_raw);
 
@@ -538,6 +541,7 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
                   const T *__restrict__ cand4, const T *__restrict__ goal, T h, T w_delta,
                   T *__restrict__ best_cost, int *__restrict__ best_idx, T *__restrict__ cost_all)
 {
+    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     __shared__ T s_cost[16];
     __shared__ int s_idx[16];
     const int e = blockIdx.x;
@@ -728,6 +732,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
                    T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log,
                    T *__restrict__ datalog, const T *__restrict__ aux)
 {
+    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS image: P tables of (x, y) pairs, then P tables of segment lengths; each table is
     // padded by one entry so that the tables of different paths start on different banks
