@@ -428,7 +428,7 @@ int vdyn_nonfinite_lanes_f32_host(VdynHandle *h, int32_t rows, int64_t n, const 
  * fit_tire_wheel: interpolation at the Chebyshev nodes of [0, 1], rounded to float).  Returns VDYN_OK if the fp32
  * Horner evaluation passed the library's own check (|error of sin(C atan x)| <= 5e-7 for every x and relative
  * error of sin(C atan x) / x <= 5e-7 for x <= sqrt(3)) -- the fp32 lane kernels of a handle use the fit only if
- * all four wheels pass and 0 <= C <= 2, B >= 0, and keep the atan -> sine chain otherwise -- or VDYN_ERR_ARG
+ * all four wheels pass and every B >= 0, and keep the atan -> sine chain otherwise -- or VDYN_ERR_ARG
  * (coef is still filled in). */
 int vdyn_tire_fit_f32(double C, float *coef);
 /* The same for the fp64 step: coef [19], degree 18, checked to 4e-15.  The fp64 kernels carry ONE set of

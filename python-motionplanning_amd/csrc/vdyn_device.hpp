@@ -86,13 +86,12 @@ template <> struct Math<float, false> {
     static __device__ __forceinline__ void sincos_steer(float d, float *s, float *c, bool &ok) { sincos(d, s, c, ok); }
     static __device__ __forceinline__ float rcp(float x) { return fm::rcp(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return fm::rsq(x); }
-    // sin(C atan(x)), inv_x = 1/x.  CS: the host guarantees 0 <= C <= 2 and B >= 0, so
-    // the argument of sin lies in [0, pi] and the reflection form applies.
+    // sin(C atan(x)), inv_x = 1/x: the general chain (any C, any sign of x).  CS kernels never get here -- their
+    // FAST step is the fitted chain (vdyn_packed.hpp) -- so the flag selects nothing.
     template <bool CS>
     static __device__ __forceinline__ float sin_c_atan(float C, float x, float inv_x)
     {
-        const float y = C * fm::atan_rcp(x, inv_x);
-        return CS ? fm::sin_0_pi(y) : fm::sin_mid(y);
+        return fm::sin_mid(C * fm::atan_rcp(x, inv_x));
     }
     static __device__ __forceinline__ void sincos(float x, float *s, float *c, bool &ok)
     {
@@ -135,8 +134,7 @@ template <> struct Math<double, false> {
     template <bool CS>
     static __device__ __forceinline__ double sin_c_atan(double C, double x, double inv_x)
     {
-        const double y = C * fm64::atan_rcp(x, inv_x);
-        return CS ? fm64::sin_0_pi(y) : fm64::sin_mid(y);
+        return fm64::sin_mid(C * fm64::atan_rcp(x, inv_x));       // general chain only: CS takes the fit (tire_force)
     }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c, bool &ok)
     {

@@ -96,8 +96,8 @@ __device__ __forceinline__ void stage_control_table_pre(T *__restrict__ tab, con
 // H zero-order-hold RK4 steps per lane (the loop of drive.py:114,141-143 with
 // vehicle_model.py:427-445 inside).  DIAG additionally returns the last step's
 // state_dot / outputs (used for H = 1: the planar_model_RK4 drop-in).
-// CS: Pacejka shape factors in [0, 2] and B >= 0 (true of any realistic tire, and of the
-// reference's 1.5047): sin's argument stays in [0, pi] and takes the short reflection form.
+// CS: every B >= 0 and the handle's tire fits validated (lane_cs below; true of any realistic tire, and of the
+// reference's B = 20.6, C = 1.5047): the FAST step takes the fitted chain (TireFit, vdyn_device.hpp).
 // k = 2 tables staged in LDS carry (sin, cos) of the steering angle per entry (not for the
 // diagnostic single-step variant, which is launch-latency bound)
 template <int K, int LAYOUT, bool DIAG> constexpr bool rollout_table_pre() { return K == 2 && LAYOUT == 1 && !DIAG; }
@@ -1407,19 +1407,19 @@ DevParams<T> make_dev_params(const VdynParams &p, const double *mu4)
     return d;
 }
 
-static bool shape_factors_small(const VdynParams &p)
+static bool stiffness_nonnegative(const VdynParams &p)
 {
     for (int i = 0; i < 4; ++i)
-        if (!(p.C[i] >= 0.0 && p.C[i] <= 2.0 && p.B[i] >= 0.0)) return false;
+        if (!(p.B[i] >= 0.0)) return false;      // the fitted chain carries B s_y as -vy |B / vx| (quirk Q4)
     return true;
 }
 
-// The CS flag of the lane-per-rollout kernels (and of the fp64 wheel-parallel one): shape factors in the short-form
-// range and a fit -- the FAST step then runs the handle's fitted tire chain -- that passed its check.
+// The CS flag of the kernels: the FAST step runs the handle's fitted tire chain.  Needs B >= 0 on every wheel and
+// fits that passed their check (any C for which they do: 0 up to about 2.9; fp64 also the same C on all wheels).
 template <typename T>
 static bool lane_cs(const VdynParams &p)
 {
-    if (!shape_factors_small(p)) return false;
+    if (!stiffness_nonnegative(p)) return false;
     return std::is_same<T, float>::value ? tire_fit(p).ok : tire_fit(p).ok64;
 }
 

@@ -221,7 +221,7 @@ __device__ __forceinline__ void pacejka_g2x2(const f2 *const W[2], const f2 q1[2
 
 // All four tires (vehicle_model.py:274-373, as tire_force in vdyn_device.hpp): index 0 = front
 // pair (always steered), index 1 = rear pair (steered only with k = 12 controls).
-// CS (0 <= C <= 2, B >= 0 and the handle's fit validated): the slips are carried pre-multiplied by B and
+// CS (B >= 0 and the handle's fit validated): the slips are carried pre-multiplied by B and
 // s_x mu / s = (B s_x) G(B s) comes from pacejka_g2x2 -- no 1/s, no s at all.
 // s[] (DIAG only) is the combined slip itself.
 template <bool REAR_STEERED, bool CS, bool DIAG>

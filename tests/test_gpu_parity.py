@@ -983,13 +983,17 @@ def test_fleet_256_classes_fp64_shared_controls(gpu_vm, pkg, oracle, workloads):
 
 
 def test_general_tire_shape_path(gpu_vm, pkg, oracle, workloads):
-    """Tire sets outside the reflection form of the FAST step (a shape factor above 2, a negative
-    stiffness factor: kernel variant CS = false, full pi-reduction and signed atan) through the plain
-    rollout kernels (LDS-shared and per-rollout controls), fp64 and fp32, against the oracle."""
+    """Tire sets the fitted chain of the FAST step does not take (shape factors whose fit fails its check, a negative
+    stiffness factor: kernel variant CS = false, atan polynomial + pi-reduced sine, signed) and one it does take
+    although sin's argument passes pi (C = 2.3 / 2.6), through the plain rollout kernels (LDS-shared and per-rollout
+    controls), fp64 and fp32, against the oracle."""
     VP = pkg.VehicleParameters
-    a, b = VP(CFL=2.3), VP(BFL=-18.0)
-    a.CRL = a.CRR = 2.6                                                # per-wheel overrides, as vehicle_model.py:237-242 does
-    for veh in (a, b):
+    a, b, c = VP(CFL=2.95), VP(BFL=-18.0), VP(CFL=2.3)
+    a.CRL = a.CRR = 3.1                                                # per-wheel overrides, as vehicle_model.py:237-242 does
+    c.CRL = c.CRR = 2.6
+    assert not pkg.VehicleModel.tire_fit(2.95)[1] and not pkg.VehicleModel.tire_fit(3.1)[1]
+    assert pkg.VehicleModel.tire_fit(2.3)[1] and pkg.VehicleModel.tire_fit(2.6)[1]
+    for veh in (a, b, c):
         n, H, dt = 1500, 80, 1e-3
         s0, tab, pid = workloads.config3(n, H, np.float64)
         tab[:, :, 0] *= 6.0                                            # steering up to 0.36 rad: slips beyond B s = 1
