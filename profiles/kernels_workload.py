@@ -55,7 +55,7 @@ def build(case, pkg, torch, dev):
         if case.endswith("wheel"):
             vm = VM(2.906, np.deg2rad(30), 1e-3, device=0, lanes_per_rollout=4)
         return (lambda: vm.rollout(s2d, c2d)), dict(
-            kernel=("rollout_quad_kernel<double, 2, 0, true>" if case.endswith("wheel")
+            kernel=("rollout_quad_kernel<double, 2, 0, true, false" if case.endswith("wheel")
                     else "rollout_kernel<double, 2, 0, false, true"),
             steps_per_lane=H, vehicle_steps=4096 * H, algo_bytes=192 * 4096 + 16 * 4096 * H, dynamic_lds_bytes=0)
     if case == "config5_mpc":
