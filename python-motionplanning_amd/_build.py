@@ -18,7 +18,9 @@ LIB_PATH = os.environ.get("VDYN_LIB_PATH") or os.path.join(PKG_DIR, "libvdyn_hip
 # One wave per SIMD is the operating point of these kernels: schedule for instruction-level
 # parallelism, not for occupancy.  A/B at the sustained clock (three runs each, +-0.2 %): the fp32
 # kernels are fastest under max-ilp (headline -1.7 % against the default strategy), the fp64 ones
-# under iterative-ilp (configs[1] 1.02 -> 0.86 ms) -- hence one translation unit per precision.
+# under iterative-ilp (configs[1] 1.02 -> 0.86 ms) -- hence one translation unit per precision.  Re-measured with
+# the fitted tire chain (round 2, one box): headline max-ilp 0.1536-0.1542 ms, iterative-ilp 0.1542, default
+# (max-occupancy) 0.1548, iterative-minreg 0.1713; closed loop 0.317 / 0.330 / 0.313 / 0.390.
 SOURCES = [("vdyn_kernels_f32.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
            ("vdyn_kernels_f64.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
            ("vdyn_capi.hip", [])]
