@@ -375,6 +375,7 @@ def run(args, compute_factory=None):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rollouts_per_s": n_total * args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
+        "host_wait": "poll" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupt",
         "prewarm": {"ms": args.prewarm_ms, "launches": prewarm_launches,
                     "why": "GPU clock ramp after idle, before the W untimed warm-up steps"},
         # the same job without the exchange step (SURVEY 8d config 4 asks for both): rank 0's kernel time only
@@ -451,6 +452,12 @@ def run(args, compute_factory=None):
 
 def main():
     args = parse()
+    # Host waits poll the completion signal instead of sleeping on an interrupt (ROCr reads this when it starts, so
+    # it is set before anything imports torch or touches HIP, and the launcher's children inherit it).  A 0.15 ms
+    # step is short against an interrupt wake-up: K = 20, W = 5 gives 0.1554 instead of 0.1572 ms per step with it,
+    # and the event-pair kernel time moves the same 1.2 % (the dispatches follow each other more closely).  The
+    # price is a spinning host thread per process while it waits.  Export HSA_ENABLE_INTERRUPT=1 to measure without.
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # typed as `python3 bench.py --gpus N`: become the launcher (nothing below has touched HIP)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
