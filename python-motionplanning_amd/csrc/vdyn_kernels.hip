@@ -945,12 +945,12 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
     const T *ob = obst + (int64_t)e * obst_ego_stride;
     // collision_in given: the caller already has the flags (select_best_path_index alone)
     if (threadIdx.x < kMaxPaths)
-        s_coll[threadIdx.x] = (collision_in != nullptr && threadIdx.x < P)
+        s_coll[threadIdx.x] = (collision_in != nullptr && (int)threadIdx.x < P)
                                   ? (collision_in[(int64_t)e * P + threadIdx.x] ? 0 : 1) : 0;
     // validity (nullable [E][P]): spirals the planner dropped (local_planner.py:317-321) are ABSENT from the
     // reference's path list -- never selectable and no contribution to anyone's proximity penalty
     if (threadIdx.x < kMaxPaths)
-        s_valid[threadIdx.x] = threadIdx.x < P && (validity == nullptr || validity[(int64_t)e * P + threadIdx.x] != 0);
+        s_valid[threadIdx.x] = (int)threadIdx.x < P && (validity == nullptr || validity[(int64_t)e * P + threadIdx.x] != 0);
     if (collision_in != nullptr) M = 0;
 
     for (int m0 = 0; m0 < M; m0 += chunk) {
@@ -979,7 +979,7 @@ select_best_path_kernel(int E, int P, int L, const T *__restrict__ x, const T *_
     }
     __syncthreads();
     // :134-203
-    if (threadIdx.x < P) {
+    if ((int)threadIdx.x < P) {
         const int64_t o = (int64_t)e * ego_stride + (int64_t)threadIdx.x * path_stride +
                           (int64_t)(L - 1) * point_stride;
         s_ex[threadIdx.x] = x[o];
