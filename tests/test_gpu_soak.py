@@ -1,0 +1,67 @@
+"""GPU (-m gpu): randomised states, controls and tire sets far outside the benchmark's envelope -- speeds from -30 to
+40 m/s (reversing vehicles), wheel speeds from locked to twice the rolling speed and of either sign, steering to
++-0.9 rad (beyond the FAST step's pi/4: the SAFE redo), torques to +-1500 N m, side-slip of metres per second,
+shape factors 0.3 .. 2.7 shared or per wheel, k = 2 and k = 12 controls -- lane-per-rollout and wheel-parallel
+kernels, fp64 and fp32, against the oracle.
+
+The reference's explicit RK4 is unstable where the wheel-slip dynamics are stiff (low speed): such a rollout turns
+1e-13 into 1e-2 within forty steps in ANY arithmetic and says nothing about a kernel.  Every rollout is therefore
+integrated twice by the oracle, the second time from an initial state perturbed by 1e-13, and only rollouts that
+amplify the perturbation by less than 1e3 are compared (most are: the filter drops a few per cent)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RW = 0.308309813617345
+
+
+@pytest.mark.parametrize("seed", [1, 7])
+def test_random_envelope_against_oracle(pkg, oracle, seed):
+    rng = np.random.default_rng(seed)
+    VP = pkg.VehicleParameters
+    worst64 = worst32 = 0.0
+    compared = total = 0
+    for case in range(24):
+        veh = VP(BFL=float(rng.uniform(8, 30)), CFL=float(rng.uniform(0.3, 2.7)))
+        if case % 3 == 0:
+            for w in ("FL", "FR", "RL", "RR"):
+                setattr(veh, "C" + w, float(rng.uniform(0.3, 2.7)))
+        n, H, dt = 512, int(rng.integers(5, 60)), float(rng.choice([1e-3, 5e-4, 2e-3]))
+        s0 = np.zeros((12, n))
+        s0[0] = rng.uniform(-30, 40, n)
+        s0[1] = rng.normal(0, 2.0, n)
+        s0[2] = rng.normal(0, 1.0, n)
+        s0[3:7] = s0[0][None, :] / RW * rng.uniform(0.0, 2.0, (4, n)) * rng.choice([1, 1, 1, -1], (4, n))
+        s0[7] = rng.uniform(-50, 50, n)
+        s0[8:10] = rng.uniform(-500, 500, (2, n))
+        s0[10:12] = rng.normal(0, 3.0, (2, n))
+        if rng.integers(0, 2):
+            c = np.stack([rng.uniform(-0.9, 0.9, (H, n)), rng.uniform(-1500, 1500, (H, n))], axis=1)
+        else:
+            c = np.concatenate([rng.uniform(-0.9, 0.9, (H, 4, n)), rng.uniform(-1500, 1500, (H, 4, n)),
+                                rng.uniform(0.2, 1.2, (H, 4, n))], axis=1)
+        p = oracle.params_from(veh)
+        with np.errstate(all="ignore"):
+            want = oracle.rollout(p, s0, c, dt)
+            pert = oracle.rollout(p, s0 * (1 + 1e-13 * rng.standard_normal(s0.shape)), c, dt)
+            o32 = oracle.rollout(p, s0.astype(np.float32), c.astype(np.float32), dt).astype(np.float64)
+        scale = np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-300)
+        amp = (np.abs(pert - want) / scale).max(axis=0) / 1e-13
+        tame = np.isfinite(want).all(axis=0) & (np.abs(want).max(axis=0) < 1e5) & np.isfinite(amp) & (amp < 1e3)
+        total += n
+        compared += int(tame.sum())
+        for lanes in (1, 4):
+            vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, params=veh, device=0, lanes_per_rollout=lanes)
+            got = vm.rollout(s0, c)
+            assert np.isfinite(got[:, tame]).all(), (case, lanes)
+            worst64 = max(worst64, float((np.abs(got[:, tame] - want[:, tame]) / scale).max()))
+            g32 = vm.rollout(s0.astype(np.float32), c.astype(np.float32)).astype(np.float64)
+            t32 = tame & np.isfinite(o32).all(axis=0) & np.isfinite(g32).all(axis=0)
+            e32 = float((np.abs(g32[:, t32] - want[:, t32]) / scale).max())
+            f32 = float((np.abs(o32[:, t32] - want[:, t32]) / scale).max())
+            worst32 = max(worst32, e32 / max(f32, 1e-6))      # against what the plain-C float oracle loses on the same rollouts
+    assert compared > 0.8 * total, (compared, total)
+    assert worst64 <= 1e-10, worst64                          # amplification < 1e3 on rounding of a few 1e-16
+    assert worst32 <= 6.0, worst32
+    print(f"\n  seed {seed}: {compared}/{total} rollouts compared, fp64 {worst64:.1e}, fp32 {worst32:.1f} x the float oracle's own error")
