@@ -173,6 +173,33 @@ def pmc_summary():
         return {}
 
 
+def counter_fields(pmc, build_id, steps_per_launch, kern_s):
+    """The counter-derived part of `roofline` -- HBM traffic per launch and the issue-slot view -- from a committed
+    PMC summary, but ONLY when that summary was taken on the very code objects this process loaded
+    (`build_id` = vdyn_build_id() of the library, stored in the summary by profiles/summarize.py).  Any other summary
+    (no id, another build) gives {"traffic": None, "pmc_stale": True, ...}: stale counters are never reported."""
+    src = "profiles/pmc_summary.json (" + str(pmc.get("tag")) + ")"
+    if not pmc:
+        return {"traffic": None}
+    if not build_id or pmc.get("build_id") != build_id:
+        return {"traffic": None, "pmc_stale": True, "pmc_source": src,
+                "pmc_build_id": pmc.get("build_id"), "loaded_build_id": build_id}
+    out = {"traffic": pmc.get("hbm_bytes_per_launch"), "pmc_stale": False, "pmc_source": src}
+    ipw = pmc.get("valu_insts_per_wave_per_rk4_step")
+    if ipw:
+        # issue-slot form of the same roofline: measured VALU wave-instructions per RK4 step
+        # (SQ_INSTS_VALU / SQ_WAVES / H) x wave-steps per second, against 1024 SIMDs issuing
+        # one wave64 VALU instruction per 2 cycles at 2.4 GHz; a lone wave per SIMD (what
+        # 65536 rollouts give) cannot issue faster than one per 4 cycles = 0.5 of that peak
+        issue = ipw * (steps_per_launch / 64.0) / kern_s
+        peak_issue = 1024 * 2.4e9 / 2
+        out.update({
+            "valu_insts_per_wave_step": ipw, "cycles_per_inst": pmc.get("wave_cycles_per_valu_inst"),
+            "issue_rate": issue, "issue_peak": peak_issue, "issue_frac": issue / peak_issue,
+            "issue_frac_of_one_wave_per_simd_ceiling": issue / (peak_issue / 2)})
+    return out
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -269,7 +296,6 @@ def run(args, compute_factory=None):
     dev = cp.device
     collective = world > 1 or args.force_collective
     if collective:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
@@ -380,7 +406,8 @@ def run(args, compute_factory=None):
                     "why": "GPU clock ramp after idle, before the W untimed warm-up steps"},
         # the same job without the exchange step (SURVEY 8d config 4 asks for both): rank 0's kernel time only
         "value_excluding_collective": n_total * H / kern_s,
-        "world_seen": sh.world, "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
+        "world_seen": sh.world, "dist_backend": getattr(cp, "backend", None) if collective else None,
+        "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
         "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
                                                  "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok},
         "config": {
@@ -394,14 +421,16 @@ def run(args, compute_factory=None):
         },
     }
     if rank == 0:
-        pmc = pmc_summary() if on_gpu else {}
+        build_id = pkg._lib.build_id() if on_gpu else None
+        out["build_id"] = build_id
+        cf = counter_fields(pmc_summary() if on_gpu else {}, build_id, steps_per_launch, kern_s)
         # the binding roofline of this kernel is VALU issue, priced as 850 flop per
         # vehicle-step against the fp32 vector peak
         tf = FLOP_PER_STEP * steps_per_launch / kern_s / 1e12
         algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * n_local
         out["roofline"] = {
             "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / VALU_PEAK_TFLOPS, "traffic": pmc.get("hbm_bytes_per_launch"),
+            "frac": tf / VALU_PEAK_TFLOPS, "traffic": None,
             "flop_per_vehicle_step": FLOP_PER_STEP, "kernel": "rollout_kernel<float,2,LDS-shared>",
             "kernel_ms": kern_s * 1e3, "kernel_ms_source": "isolated per-launch events after the timed region" if collective
             else "one HIP event pair around the K timed launches / K",
@@ -413,23 +442,11 @@ def run(args, compute_factory=None):
         }
         if args.dump_durations:
             out["roofline"]["kernel_ms_all"] = [round(float(x) * 1e3, 4) for x in durs]
-        ipw = pmc.get("valu_insts_per_wave_per_rk4_step")
-        if ipw:
-            # issue-slot form of the same roofline: measured VALU wave-instructions per RK4 step
-            # (SQ_INSTS_VALU / SQ_WAVES / H) x wave-steps per second, against 1024 SIMDs issuing
-            # one wave64 VALU instruction per 2 cycles at 2.4 GHz; a lone wave per SIMD (what
-            # 65536 rollouts give) cannot issue faster than one per 4 cycles = 0.5 of that peak
-            issue = ipw * (steps_per_launch / 64.0) / kern_s
-            peak_issue = 1024 * 2.4e9 / 2
-            out["roofline"].update({
-                "valu_insts_per_wave_step": ipw, "cycles_per_inst": pmc.get("wave_cycles_per_valu_inst"),
-                "issue_rate": issue, "issue_peak": peak_issue, "issue_frac": issue / peak_issue,
-                "issue_frac_of_one_wave_per_simd_ceiling": issue / (peak_issue / 2),
-                "pmc_source": "profiles/pmc_summary.json (" + str(pmc.get("tag")) + ")"})
+        out["roofline"].update(cf)
         ach = algo_bytes / kern_s / 1e9
         out["roofline_hbm"] = {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
+            "frac": ach / HBM_PEAK_GBS, "traffic": cf.get("traffic"),
             "algorithmic_bytes_per_launch": algo_bytes,
         }
         if world == 1 and on_gpu and not args.no_extra and not args.strong:
@@ -458,6 +475,9 @@ def main():
     # and the event-pair kernel time moves the same 1.2 % (the dispatches follow each other more closely).  The
     # price is a spinning host thread per process while it waits.  Export HSA_ENABLE_INTERRUPT=1 to measure without.
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+    # dmabuf IPC (the only mode the host driver supports) for RCCL and hipIpc*MemHandle: ROCr reads this at start-up
+    # too, so it is set here for BOTH launch forms (torchrun-started ranks and our own children), not after HIP is up
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # typed as `python3 bench.py --gpus N`: become the launcher (nothing below has touched HIP)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))

@@ -82,6 +82,11 @@ typedef struct VdynCtrlGains {
 typedef struct VdynHandle VdynHandle;
 
 int vdyn_abi_version(void);
+/* Identity of the code objects in this library: the first 16 hex digits of the SHA-256 of the sources and compiler
+ * flags it was built from (python-motionplanning_amd/_build.py, source_hash()).  Measurement only:
+ * profiles/summarize*.py store it beside the counters they condense, and bench.py reports a committed counter
+ * summary as stale when it was taken on another build.  No reference counterpart. */
+const char *vdyn_build_id(void);
 int vdyn_device_count(void);
 
 /* VehicleParameters() with its default arguments (vehicle_model.py:18-22). */

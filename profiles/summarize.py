@@ -27,7 +27,21 @@ def find(sub, pattern):
     return hits[0] if hits else None
 
 
-summary = {"tag": tag, "kernel": None}
+def loaded_build_id():
+    """vdyn_build_id() of the library these counters were taken on (the summary runs on the same box, right after
+    the collection): what bench.py later compares with the library IT loaded."""
+    import ctypes
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        lib = ctypes.CDLL(importlib.import_module("python-motionplanning_amd._build").LIB_PATH)
+        lib.vdyn_build_id.restype = ctypes.c_char_p
+        return lib.vdyn_build_id().decode()
+    except (OSError, AttributeError):
+        return None
+
+
+summary = {"tag": tag, "build_id": loaded_build_id(), "kernel": None}
 ks = find("kt", "*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))

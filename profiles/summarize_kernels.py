@@ -22,7 +22,21 @@ def find(base, sub, pattern):
     return hits[0] if hits else None
 
 
-result = {"tag": tag, "cases": {}}
+def loaded_build_id():
+    """vdyn_build_id() of the library these counters were taken on (the summary runs on the same box, right after
+    the collection): what bench.py later compares with the library IT loaded."""
+    import ctypes
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        lib = ctypes.CDLL(importlib.import_module("python-motionplanning_amd._build").LIB_PATH)
+        lib.vdyn_build_id.restype = ctypes.c_char_p
+        return lib.vdyn_build_id().decode()
+    except (OSError, AttributeError):
+        return None
+
+
+result = {"tag": tag, "build_id": loaded_build_id(), "cases": {}}
 for mf in sorted(glob.glob(os.path.join(out, "*", "manifest.json"))):
     base = os.path.dirname(mf)
     man = json.load(open(mf))

@@ -43,6 +43,23 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_hash(extra_flags=()):
+    """First 16 hex digits of the SHA-256 of everything the code objects depend on: every file under csrc/, the
+    public header and the compiler flags.  Compiled into the library (vdyn_build_id) so that a counter summary under
+    profiles/ can be tied to the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.normpath(os.path.join(PKG_DIR, os.pardir, "include", "vdyn.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(repr((HIPCC_FLAGS, SOURCES, tuple(extra_flags))).encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -60,11 +77,14 @@ def build(force=False, verbose=False, extra_flags=()):
     hipcc = hipcc_path()
     objdir = os.path.join(PKG_DIR, "build", os.path.basename(LIB_PATH) + ".d")
     os.makedirs(objdir, exist_ok=True)
+    build_id = source_hash(extra_flags)
 
     def compile_one(item):
         src, flags = item
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, *HIPCC_FLAGS, *flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if src == "vdyn_capi.hip":
+            cmd.insert(1, f'-DVDYN_BUILD_ID="{build_id}"')
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

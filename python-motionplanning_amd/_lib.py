@@ -45,6 +45,7 @@ _i32, _i64, _dbl, _int = C.c_int32, C.c_int64, C.c_double, C.c_int
 # name -> (restype, argtypes); one entry per symbol include/vdyn.h declares
 SIGNATURES = {
     "vdyn_abi_version": (_int, []),
+    "vdyn_build_id": (C.c_char_p, []),
     "vdyn_device_count": (_int, []),
     "vdyn_params_default": (None, [C.POINTER(VdynParams)]),
     "vdyn_create": (_int, [C.POINTER(VdynParams), _int, C.POINTER(_vp)]),
@@ -158,6 +159,11 @@ def load():
         raise VdynError(VDYN_ERR_ARG, "libvdyn_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def build_id():
+    """Identity of the loaded code objects (include/vdyn.h, vdyn_build_id)."""
+    return load().vdyn_build_id().decode()
 
 
 def default_params():

@@ -69,6 +69,11 @@ extern "C" {
 
 int vdyn_abi_version(void) { return VDYN_ABI_VERSION; }
 
+#ifndef VDYN_BUILD_ID
+#define VDYN_BUILD_ID "unknown"
+#endif
+const char *vdyn_build_id(void) { return VDYN_BUILD_ID; }
+
 int vdyn_device_count(void)
 {
     int n = 0;

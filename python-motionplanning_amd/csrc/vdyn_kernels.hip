@@ -406,7 +406,7 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
     s.x = state0[8 * n + r];
     s.y = state0[9 * n + r];
     T ax = state0[10 * n + r], ay = state0[11 * n + r];
-    const T mu_k2 = q == 0 ? P.mu[0] : q == 1 ? P.mu[1] : q == 2 ? P.mu[2] : P.mu[3];
+    const T mu_k2 = pick_wheel(P.mu[0], P.mu[1], P.mu[2], P.mu[3], q);
 
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);

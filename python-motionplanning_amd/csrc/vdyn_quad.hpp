@@ -62,6 +62,18 @@ struct WheelLane {
     bool front;
 };
 
+// Wheel q's entry of a per-wheel constant.  The four values are made opaque first: left visible, the select chain
+// over P.X[0..3] is folded into ONE load at a lane-dependent index, and an indexed read of a by-value kernel argument
+// needs the argument in memory -- the whole DevParams struct was copied to scratch in the prologue of every
+// wheel-parallel kernel (264 B fp32 / 392 B fp64 per lane; profiles/r02f: config2_f64_wheel wrote 17 x its
+// algorithmic bytes).  Opaque scalars stay in SGPRs and the chain stays three v_cndmask.
+template <typename T>
+__device__ __forceinline__ T pick_wheel(T a, T b, T c, T d, int q)
+{
+    asm("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+    return q == 0 ? a : q == 1 ? b : q == 2 ? c : d;
+}
+
 template <typename T>
 __device__ __forceinline__ WheelLane<T> make_wheel_lane(const DevParams<T> &P, int q)
 {
@@ -70,9 +82,9 @@ __device__ __forceinline__ WheelLane<T> make_wheel_lane(const DevParams<T> &P, i
     w.front = q < 2;
     w.side = right ? T(1) : T(-1);
     w.lever = w.front ? P.a : -P.b;
-    w.B = q == 0 ? P.B[0] : q == 1 ? P.B[1] : q == 2 ? P.B[2] : P.B[3];
-    w.invB = q == 0 ? P.invB[0] : q == 1 ? P.invB[1] : q == 2 ? P.invB[2] : P.invB[3];
-    w.C = q == 0 ? P.C[0] : q == 1 ? P.C[1] : q == 2 ? P.C[2] : P.C[3];
+    w.B = pick_wheel(P.B[0], P.B[1], P.B[2], P.B[3], q);
+    w.invB = pick_wheel(P.invB[0], P.invB[1], P.invB[2], P.invB[3], q);
+    w.C = pick_wheel(P.C[0], P.C[1], P.C[2], P.C[3], q);
     w.Fz0 = w.front ? P.Fz0F : P.Fz0R;
     const T dfx = right ? P.DfzxR : P.DfzxL;
     w.kx = w.front ? -dfx : dfx;

@@ -79,7 +79,7 @@ struct QuadEngine<float> {
         inv_Jw = iJ;
         neg_rw_Jw = -r_w * iJ;
 #pragma unroll
-        for (int i = 0; i <= kTireFitDeg; ++i) fw[i] = q == 0 ? P.W[i][0] : q == 1 ? P.W[i][1] : q == 2 ? P.W[i][2] : P.W[i][3];
+        for (int i = 0; i <= kTireFitDeg; ++i) fw[i] = pick_wheel(P.W[i][0], P.W[i][1], P.W[i][2], P.W[i][3], q);
     }
 
     __device__ __forceinline__ f2 sincos_k(float r) const

@@ -151,6 +151,9 @@ class PeerExchange:
                                     device=like.device)
         self.recv.zero_()
         self.send = like.new_zeros((self.rows, sh.n_pad)) if sh.n_local != sh.n_pad else None
+        # the zero fill must have RUN before a peer can learn this buffer's handle: its first push could otherwise
+        # land before the fill and be wiped by it
+        torch.cuda.synchronize(like.device)
         # every rank learns every rank's handle; its own buffer is used through the local pointer
         blobs = [None] * sh.world
         if sh.world > 1:
@@ -187,11 +190,18 @@ class PeerExchange:
             self._pending = None
 
     def result(self) -> torch.Tensor:
+        """[rows][n_units] of the last exchange, a private copy.  Collective: every rank must call it (two barriers).
+        On return no rank reads a slot any more, so any rank may ``start`` the next exchange at once."""
         self.wait()
-        if dist.is_initialized() and self.sh.world > 1:
+        multi = dist.is_initialized() and self.sh.world > 1
+        if multi:
             dist.barrier(group=self.sh.group)   # every rank has waited for its own pushes
         torch.cuda.synchronize(self.recv.device)
-        return self.sh.assemble(self.recv, self.rows)
+        out = self.sh.assemble(self.recv, self.rows)
+        torch.cuda.synchronize(self.recv.device)   # the copies out of the slots have run ...
+        if multi:
+            dist.barrier(group=self.sh.group)   # ... on every rank, before a faster peer's next push overwrites one
+        return out
 
     def close(self):
         if self._own is None:

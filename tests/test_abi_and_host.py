@@ -29,7 +29,7 @@ def lib(pkg):
 
 def test_header_symbols_all_exported(lib):
     syms = declared_symbols()
-    assert len(syms) == 12 + 2 * 26 + 6, syms          # + the six vdyn_xchg_* entry points
+    assert len(syms) == 13 + 2 * 26 + 6, syms          # + the six vdyn_xchg_* entry points; 13 incl. vdyn_build_id
     dll = ctypes.CDLL(lib.LIB_PATH)
     for s in syms:
         assert hasattr(dll, s), f"{s} declared in include/vdyn.h but not exported"
@@ -48,6 +48,8 @@ def test_library_carries_gfx950_code_only(lib):
 def test_params_struct_and_defaults(lib):
     assert ctypes.sizeof(lib.VdynParams) == 19 * 8 and ctypes.sizeof(lib.VdynCtrlGains) == 9 * 8
     assert lib.load().vdyn_abi_version() == lib.VDYN_ABI_VERSION
+    bld = importlib.import_module("python-motionplanning_amd._build")
+    assert lib.build_id() == bld.source_hash(), "the library carries the hash of the sources it was built from"
     p = lib.default_params()
     # SURVEY.md section 8(a1), measured on the reference's VehicleParameters()
     assert p.m == pytest.approx(1857.82, abs=1e-12)

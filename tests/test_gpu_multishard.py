@@ -128,3 +128,33 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
                                   path_id=torch.from_numpy(pid).to(dev)).cpu().numpy()
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"gathered_rank{r}.npy"), single), "what every rank holds == the single launch"
+
+
+@pytest.mark.parametrize("exchange,overlap", [("rccl", True), ("rccl", False), ("p2p", True)])
+def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
+    """The DEFAULT multi-GPU path of bench.py as an 8-GPU run executes it -- torch.distributed on the `nccl` backend
+    (= RCCL) with `device_id` set, `all_gather_into_tensor(async_op=True)` overlapped with the next launch
+    (distributed.AllGatherExchange), or the peer-copy exchange on the same backend -- rehearsed with ONE rank on the
+    one GPU of the box (`--force-collective`; RCCL refuses two ranks on one device, hence one).  A fresh child
+    process: nothing here re-executes a process that touched the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--force-collective", "--exchange", exchange,
+           "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--no-extra", "--no-cpu-baseline"]
+    if not overlap:
+        cmd.append("--no-overlap")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["world_seen"] == 1 and out["rollouts_total"] == 65536
+    assert out["dist_backend"] == "nccl"
+    assert out["exchange"] == {"kind": "all_gather_into_tensor" if exchange == "rccl" else "peer_copies",
+                               "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True}
+    assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
+    assert out["roofline"]["bound"] == "valu" and out["shards"] == [[0, 65536]]
