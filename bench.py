@@ -60,9 +60,12 @@ def parse(argv=None):
     ap.add_argument("--wheel-parallel", action="store_true",
                     help="four lanes per rollout (shorter serial chain for small shards; agrees with the "
                          "lane-per-rollout kernel to rounding, not bit for bit): the labelled second number of --strong")
-    ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl",
-                    help="N>1 exchange of terminal states: RCCL all-gather (default) or direct peer copies "
-                         "(hipMemcpyAsync into every peer's IPC-mapped slot on a copy stream: no CU-resident copy kernel)")
+    ap.add_argument("--exchange", choices=("auto", "rccl", "p2p"), default="auto",
+                    help="N>1 exchange of terminal states: direct peer copies (hipMemcpyAsync into every peer's "
+                         "IPC-mapped slot on copy streams: no CU-resident copy kernel) or the RCCL all-gather.  auto "
+                         "(default) = peer copies when every rank can set them up and a test exchange arrives intact "
+                         "on every rank, RCCL otherwise: with one rank the all-gather's copy kernel costs the rollout "
+                         "7.5 %% of its step, the copies 3.4 %% (profiles/r03_exchange_one_rank.json)")
     # rehearsal of the N > 1 path where only one GPU exists (tests/test_gpu_multishard.py): ranks share the listed
     # devices ("0,0": both on GPU 0), torch.distributed runs on gloo (RCCL refuses two ranks on one GPU)
     ap.add_argument("--device-map", default=None, help=argparse.SUPPRESS)
@@ -409,7 +412,8 @@ def run(args, compute_factory=None):
         "world_seen": sh.world, "dist_backend": getattr(cp, "backend", None) if collective else None,
         "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
         "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
-                                                 "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok},
+                                                 "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok,
+                                                 "requested": args.exchange, "fallback_reason": xch.fallback_reason},
         "config": {
             "workload": f"BASELINE configs[2]: {per_gpu} rollouts per GPU (ego r//7, lattice path r%7; whole egos per "
                         f"rank: {n_total} in all) x {H} RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared "
@@ -577,6 +581,31 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = (time.perf_counter() - t0) / 300
     ex["dropin_single_vehicle_step_f64"] = {"us_per_call": t * 1e6, "steps_per_s": 1.0 / t,
                                             "reference_numpy_us_per_call": 247.7}
+    # BASELINE configs[0] as a whole: one frame of Car.drive (drive.py:112-154: plan the lattice, collision check /
+    # best path, re-interpolate it to 1 cm, 100 sub-steps of Stanley + PID + RK4 with the 45-column DataLog) for ONE
+    # vehicle through the mirror drive.Car -- four launches per frame, host lists in and out -- on the reference's
+    # own two global paths and obstacle list (tests/golden/g14_global_paths.npz, generated from the reference)
+    g14p = os.path.join(ROOT, "tests", "golden", "g14_global_paths.npz")
+    if os.path.exists(g14p):
+        pkg_ = importlib.import_module("python-motionplanning_amd")
+        with np.load(g14p, allow_pickle=False) as g14:
+            frames = {}
+            for tag in ("world", "csv"):
+                px_, py_, pyaw_ = g14[tag + "_px"], g14[tag + "_py"], g14[tag + "_pyaw"]
+                car = pkg_.Car(px_[10], py_[10], pyaw_[10], px_, py_, pyaw_, 1e-4, obstacles=g14["obstacle_xy"],
+                               device=vm.device, log_frames=30)
+                for f in range(3):
+                    car.drive(f)
+                t0 = time.perf_counter()
+                for f in range(3, 23):
+                    car.drive(f)
+                frames[tag] = (time.perf_counter() - t0) / 20 * 1e3
+                assert np.isfinite(car.state).all()
+        ex["config0_car_drive_frame_f64"] = {
+            "ms_per_frame_world_path": frames["world"], "ms_per_frame_waypoints_csv": frames["csv"],
+            "launches_per_frame": 4, "sub_steps_per_frame": 100, "reference_numpy_ms_per_frame": 329.0,
+            "note": "ONE vehicle, latency-bound: host marshalling + four launches; the reference's 329 ms is "
+                    "BASELINE.md's measurement in the build container (it cannot run on the GPU box)"}
     # lattice generation: 9363 egos x 7 spirals, device optimiser, fp64
     Ego = 9363
     th = np.linspace(0.0, 2 * np.pi, 4000, endpoint=False)

@@ -468,8 +468,9 @@ int vdyn_fastmath_eval_f64_host(VdynHandle *h, int32_t fn, int64_t n, const doub
  * with a copy kernel that shares the CUs with the next rollout.  These entry points do it with
  * copies instead: every rank owns a slot buffer [world][block], exports it once (hipIpcGetMemHandle),
  * opens its peers' buffers (hipIpcOpenMemHandle) and, per step, pushes its block into slot `rank`
- * of every buffer with hipMemcpyAsync on the handle's own copy stream, ordered behind the compute
- * stream by an event.  One process per GPU; the 64-byte handles travel through whatever side
+ * of every buffer with hipMemcpyAsync on the handle's own copy streams (one per destination, up to
+ * eight: the copies to different peers travel at the same time, over different xGMI links), ordered
+ * behind the compute stream by an event.  One process per GPU; the 64-byte handles travel through whatever side
  * channel the caller has (torch.distributed.all_gather_object in distributed.PeerExchange).
  * There is no counterpart in the reference (its only parallelism is the process pool of
  * local_planner.py:369-374).                                                                    */
@@ -482,8 +483,9 @@ int vdyn_xchg_free(VdynHandle *h, void *dev_ptr);
 int vdyn_xchg_open(VdynHandle *h, const VdynIpcHandle *peer, void **peer_ptr);
 int vdyn_xchg_close(VdynHandle *h, void *peer_ptr);
 /* Copy `bytes` from src (this device) to dst[i] + dst_offset for i < n_dst, on the handle's copy
- * stream, after everything enqueued so far on `after_stream` (the compute stream; NULL = default).
- * Returns without waiting.  At most 64 destinations.                                            */
+ * streams, after everything enqueued so far on `after_stream` (the compute stream; NULL = default).
+ * Returns without waiting.  At most 64 destinations; one push in flight per handle (an error
+ * otherwise: vdyn_xchg_wait() first).                                                           */
 int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
                    uint64_t bytes, void *after_stream);
 /* Block the host until this handle's pushes have landed (a no-op when none is in flight). */

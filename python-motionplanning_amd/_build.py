@@ -63,6 +63,13 @@ def source_hash(extra_flags=()):
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
+    # the id the library was built with (written beside it at link time) against the sources as they are now:
+    # catches an edit made WHILE a build was running, which modification times alone miss
+    try:
+        if open(LIB_PATH + ".id").read().strip() != source_hash():
+            return True
+    except OSError:
+        return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
@@ -79,17 +86,30 @@ def build(force=False, verbose=False, extra_flags=()):
     os.makedirs(objdir, exist_ok=True)
     build_id = source_hash(extra_flags)
 
+    def deps_of(src):
+        # the C ABI unit sees the launchers' declarations only; the kernel units see every header
+        if src == "vdyn_capi.hip":
+            return [os.path.join(CSRC, src), os.path.join(CSRC, "vdyn_internal.hpp"), HEADERS[-1]]
+        return [os.path.join(CSRC, src)] + HEADERS
+
     def compile_one(item):
         src, flags = item
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, *HIPCC_FLAGS, *flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if src == "vdyn_capi.hip":
             cmd.insert(1, f'-DVDYN_BUILD_ID="{build_id}"')
+        # an object is reused when it is newer than everything it was compiled from and its command line is the same
+        stamp = obj + ".cmd"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd) \
+                and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps_of(src)):
+            return obj
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout)
+        with open(stamp, "w") as f:
+            f.write(" ".join(cmd))
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
@@ -101,6 +121,8 @@ def build(force=False, verbose=False, extra_flags=()):
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(LIB_PATH + ".id", "w") as f:
+        f.write(build_id + "\n")
     return LIB_PATH
 
 

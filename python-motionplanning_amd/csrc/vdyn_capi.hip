@@ -27,9 +27,13 @@ struct VdynHandle {
     void *d_count = nullptr;        // one counter (vdyn_nonfinite_lanes_*)
     void *d_cand = nullptr;         // MPC candidate table with the steering angles' (sin, cos) per entry
     size_t d_cand_bytes = 0;
-    hipStream_t copy_stream = nullptr;   // peer exchange (vdyn_xchg_*): copies run here, beside the compute stream
-    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    bool push_in_flight = false;
+    // peer exchange (vdyn_xchg_*): copies run on these streams, beside the compute stream -- one per destination
+    // (round robin beyond kCopyStreams), so that the copies to different peers can use different SDMA engines and
+    // xGMI links at the same time instead of queueing behind each other
+    static constexpr int kCopyStreams = 8;
+    hipStream_t copy_stream[kCopyStreams] = {};
+    hipEvent_t ev_ready = nullptr, ev_done[kCopyStreams] = {};
+    int push_streams = 0;           // streams the push in flight used (0: none in flight)
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -176,9 +180,11 @@ void vdyn_destroy(VdynHandle *h)
     if (h->d_aux) (void)hipFree(h->d_aux);
     if (h->d_cand) (void)hipFree(h->d_cand);
     if (h->d_count) (void)hipFree(h->d_count);
-    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (int i = 0; i < VdynHandle::kCopyStreams; ++i) {
+        if (h->copy_stream[i]) { (void)hipStreamSynchronize(h->copy_stream[i]); (void)hipStreamDestroy(h->copy_stream[i]); }
+        if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
+    }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
-    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     delete h;
 }
 
@@ -259,28 +265,32 @@ int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_
     for (int i = 0; i < n_dst; ++i)
         if (!dst[i]) return h->fail(VDYN_ERR_ARG, "xchg_push: null destination");
     VDYN_HIP(h, hipSetDevice(h->device));
-    if (!h->copy_stream) {
-        VDYN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
-        VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    if (h->push_streams != 0) return h->fail(VDYN_ERR_ARG, "xchg_push: vdyn_xchg_wait() for the previous push first");
+    const int ns = std::min<int>(n_dst, VdynHandle::kCopyStreams);
+    if (!h->ev_ready) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    for (int i = 0; i < ns; ++i) {
+        if (h->copy_stream[i]) continue;
+        VDYN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream[i], hipStreamNonBlocking));
+        VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
     }
-    VDYN_HIP(h, hipEventRecord(h->ev_ready, (hipStream_t)after_stream));      // the block is complete ...
-    VDYN_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_ready, 0));          // ... before any copy reads it
+    VDYN_HIP(h, hipEventRecord(h->ev_ready, (hipStream_t)after_stream));          // the block is complete ...
+    for (int i = 0; i < ns; ++i)
+        VDYN_HIP(h, hipStreamWaitEvent(h->copy_stream[i], h->ev_ready, 0));       // ... before any copy reads it
     for (int i = 0; i < n_dst; ++i)
         VDYN_HIP(h, hipMemcpyAsync(static_cast<char *>(dst[i]) + dst_offset, src, bytes, hipMemcpyDeviceToDevice,
-                                   h->copy_stream));
-    VDYN_HIP(h, hipEventRecord(h->ev_done, h->copy_stream));
-    h->push_in_flight = true;
+                                   h->copy_stream[i % ns]));
+    for (int i = 0; i < ns; ++i) VDYN_HIP(h, hipEventRecord(h->ev_done[i], h->copy_stream[i]));
+    h->push_streams = ns;
     return VDYN_OK;
 }
 
 int vdyn_xchg_wait(VdynHandle *h)
 {
     if (!h) return VDYN_ERR_ARG;
-    if (!h->push_in_flight) return VDYN_OK;
+    if (h->push_streams == 0) return VDYN_OK;
     VDYN_HIP(h, hipSetDevice(h->device));
-    VDYN_HIP(h, hipEventSynchronize(h->ev_done));
-    h->push_in_flight = false;
+    for (int i = 0; i < h->push_streams; ++i) VDYN_HIP(h, hipEventSynchronize(h->ev_done[i]));
+    h->push_streams = 0;
     return VDYN_OK;
 }
 
@@ -436,9 +446,9 @@ int mpc_dev(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, con
     if (!ego || !goal || !best_cost || !best_idx || (H > 0 && !cand))
         return h->fail(VDYN_ERR_ARG, "mpc_argmin: null buffer");
     VDYN_HIP(h, hipSetDevice(h->device));
-    // candidate table with (sin, cos) of the steering angles: handle-owned scratch, grown on demand
+    // candidate table with (sin, cos) of the steering angles + per-chunk partial minima: handle-owned scratch, grown on demand
     // (hipFree waits for launches still reading the old one)
-    const size_t c4 = sizeof(T) * 4 * (size_t)H * (size_t)C;
+    const size_t c4 = vdyn::mpc_scratch_bytes<T>(E, C, H);
     if (c4 > h->d_cand_bytes) {
         if (h->d_cand) { (void)hipFree(h->d_cand); h->d_cand = nullptr; h->d_cand_bytes = 0; }
         if (hipMalloc(&h->d_cand, c4) != hipSuccess) {
@@ -449,7 +459,7 @@ int mpc_dev(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, con
         h->d_cand_bytes = c4;
     }
     VDYN_HIP(h, vdyn::launch_mpc_argmin<T>(h->p, E, C, H, ego, cand, goal, dt, w_delta, best_cost,
-                                           best_idx, cost_all, static_cast<T *>(h->d_cand), (hipStream_t)stream));
+                                           best_idx, cost_all, h->d_cand, (hipStream_t)stream));
     return VDYN_OK;
 }
 

@@ -66,7 +66,9 @@ hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, c
 template <typename T>
 hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *ego, const T *cand,
                              const T *goal, double dt, double w_delta, T *best_cost, int *best_idx,
-                             T *cost_all, T *cand4 /* device scratch, H * C * 4 elements */, hipStream_t st);
+                             T *cost_all, void *scratch /* device, mpc_scratch_bytes() */, hipStream_t st);
+template <typename T>
+size_t mpc_scratch_bytes(int E, int C, int H);
 
 template <typename T>
 struct ClosedLoopArgs {

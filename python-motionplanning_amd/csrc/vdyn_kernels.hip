@@ -604,6 +604,100 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
     }
 }
 
+// The same selection with the EGOS on the lanes: a wave = 64 consecutive egos x a chunk of KC consecutive candidates,
+// run one after the other.  The candidate is then wave-uniform: its controls (delta, torque, sin delta, cos delta) are
+// one scalar load per step -- issued a step ahead, no vector-memory wait in the step at all -- where the kernel above
+// has every lane fetch its own 16-byte entry and wait for it (28 % of its cycles, profiles/r02f), and the running
+// (min, argmin) of a lane needs no cross-lane reduction.  Each wave writes its lanes' best (cost, index) of the chunk
+// to part [chunk][E]; mpc_reduce_kernel takes the minimum over the chunks in ascending order with a strict '<', so
+// the lowest index still wins ties and a NaN / inf cost never wins -- exactly the scan of the kernel above.
+//   grid = ceil(E / 64) * ceil(C / KC) waves, one wave per workgroup; KC is chosen by the launcher so that the grid is
+//   about two waves per SIMD (fp32; one for fp64) -- what the register budget of the packed step allows.
+template <typename T, bool CS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, sizeof(T) == 4 ? 2 : 1)))
+mpc_argmin_lanes_kernel(DevParams<T> P, int E, int C, int H, int KC, const T *__restrict__ ego,
+                        const T *__restrict__ cand4, const T *__restrict__ goal, T h, T w_delta,
+                        T *__restrict__ part_cost, int *__restrict__ part_idx, T *__restrict__ cost_all)
+{
+    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
+    const int ngroups = (E + 63) / 64;
+    const int grp = (int)(blockIdx.x % (unsigned)ngroups), chunk = (int)(blockIdx.x / (unsigned)ngroups);
+    const int e_raw = grp * 64 + (int)threadIdx.x;
+    const bool active = e_raw < E;
+    const int e = active ? e_raw : E - 1;       // idle lanes shadow the last ego, stores masked
+    constexpr int kNone = 0x7fffffff;
+
+    typename StepEngine<T>::State X0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) X0.set(i, ego[(int64_t)i * E + e]);
+    const T gx = goal[e], gy = goal[(int64_t)E + e];
+    StepEngine<T> eng;
+    eng.template init<true, CS>(P);
+
+    T bc = T(INFINITY);
+    int bi = kNone;
+    const int c0 = chunk * KC, c1 = min(c0 + KC, C);
+    for (int c = c0; c < c1; ++c) {             // wave-uniform
+        typename StepEngine<T>::State X = X0;
+        T dsum = T(0);
+        const T *tab = cand4 + (int64_t)c * 4;  // entry of step t at tab + t * C * 4: a scalar (uniform) address
+        const int64_t ts = (int64_t)C * 4;
+        Ctrl<T, 2> cc, c2;                      // step t + 1's controls are fetched behind step t (see rollout_kernel)
+        if (H > 0) cc.set_pre(P, tab);
+        int t = 0;
+        for (; t + 1 < H; t += 2) {             // two steps per trip, control sets ping-pong
+            c2.set_pre(P, tab + (int64_t)(t + 1) * ts);
+            VDYN_FETCH_FENCE
+            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            dsum += cc.delta[0] * cc.delta[0];
+            cc.set_pre(P, tab + (int64_t)min(t + 2, H - 1) * ts);
+            VDYN_FETCH_FENCE
+            eng.template advance_state<true, CS, 1>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+            dsum += c2.delta[0] * c2.delta[0];
+        }
+        if (t < H) {
+            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            dsum += cc.delta[0] * cc.delta[0];
+        }
+        const T dx = X.get(8) - gx, dy = X.get(9) - gy;
+        const T cost = sqrt_t(dx * dx + dy * dy) + w_delta * dsum;
+        if (cost_all != nullptr && active) cost_all[(int64_t)e * C + c] = cost;
+        if (cost < bc) { bc = cost; bi = c; }   // strict '<': lowest index wins ties; NaN/inf never win
+    }
+    if (active) {
+        part_cost[(int64_t)chunk * E + e] = bc;
+        part_idx[(int64_t)chunk * E + e] = bi;
+    }
+}
+
+// part [nchunks][E] -> (best_cost, best_idx)[E]: chunks in ascending order (= ascending candidate index), strict '<'.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+mpc_reduce_kernel(int E, int nchunks, const T *__restrict__ part_cost, const int *__restrict__ part_idx,
+                  T *__restrict__ best_cost, int *__restrict__ best_idx)
+{
+    const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (e >= E) return;
+    constexpr int kNone = 0x7fffffff, kFly = 8;
+    T bc = T(INFINITY);
+    int bi = kNone;
+    for (int k0 = 0; k0 < nchunks; k0 += kFly) {
+        T pc[kFly];
+        int pi[kFly];
+#pragma unroll
+        for (int k = 0; k < kFly; ++k) {
+            const int kk = min(k0 + k, nchunks - 1);
+            pc[k] = part_cost[(int64_t)kk * E + e];
+            pi[k] = part_idx[(int64_t)kk * E + e];
+        }
+#pragma unroll
+        for (int k = 0; k < kFly; ++k)
+            if (k0 + k < nchunks && pc[k] < bc) { bc = pc[k]; bi = pi[k]; }
+    }
+    best_cost[e] = bc;
+    best_idx[e] = bi == kNone ? -1 : bi;
+}
+
 // Auxiliary waypoint tables for the controllers when the P tables do not fit LDS: segment lengths
 // seg[j][P] and one bounding circle per 32 waypoints bnd[b][4][P], both TRANSPOSED (table index
 // fastest) so that the lanes of a wave -- vehicles with consecutive tables -- read neighbouring
@@ -613,19 +707,18 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
 constexpr int kAuxTP = 32;                 // tables per tile
 constexpr int kAuxTJ = 2 * kWpBlock;       // waypoints per tile = two bounding circles per table
 
-//   LDSIMG = false: seg [j][P], bnd [b][4][P]               (transposed, read in place by the lanes)
-//   LDSIMG = true:  seg [P][Wmax + 1], bnd [P][nb][4]         (the closed loop's LDS image: every
-//                   workgroup copies it instead of recomputing it 256 times over)
-template <typename T, bool LDSIMG>
+//   seg [j][P], bnd [b][4][P]   (transposed, read in place by the lanes).  Tables that fit LDS need none of this:
+//   closed_loop_kernel builds its LDS image from the tables alone.
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
 waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ wcount, int Pn, T *__restrict__ aux)
 {
     __shared__ T tx[kAuxTP][kAuxTJ + 2], ty[kAuxTP][kAuxTJ + 2];   // column 0 = the waypoint before the tile
     const int nb = (Wmax + kWpBlock - 1) / kWpBlock;
-    const int64_t seg_len = LDSIMG ? (int64_t)(Wmax + 1) * Pn : (int64_t)Wmax * Pn;
+    const int64_t seg_len = (int64_t)Wmax * Pn;
     T *seg = aux, *bnd = aux + seg_len;
-    const int64_t ss_j = LDSIMG ? 1 : Pn, ss_p = LDSIMG ? Wmax + 1 : 1;         // seg[j * ss_j + p * ss_p]
-    const int64_t bs = LDSIMG ? 1 : Pn, bp = LDSIMG ? (int64_t)nb * 4 : 1;       // bnd[(4 b + c) * bs + p * bp]
+    const int64_t ss_j = Pn, ss_p = 1;         // seg[j * ss_j + p * ss_p]
+    const int64_t bs = Pn, bp = 1;             // bnd[(4 b + c) * bs + p * bp]
     const int tiles_j = (Wmax + kAuxTJ - 1) / kAuxTJ;
     const int p0 = (blockIdx.x / tiles_j) * kAuxTP, j0 = (blockIdx.x % tiles_j) * kAuxTJ;
     // read: thread -> (table row, waypoint) with the waypoint fastest
@@ -682,12 +775,12 @@ waypoint_aux_kernel(const T *__restrict__ wp, int Wmax, const int *__restrict__ 
 // fp32 controllers search the lookahead point on the CUMULATIVE arc length (vdyn_controls.hpp): turn the
 // segment lengths of waypoint_aux_kernel into running sums, in place.  One wave per table: every lane sums
 // its chunk, a wave scan gives the chunk offsets, a second pass writes the running sums.
-template <typename T, bool LDSIMG>
+template <typename T>
 __global__ void __launch_bounds__(64)
 waypoint_cumsum_kernel(int Wmax, int Pn, T *__restrict__ aux)
 {
     const int p = blockIdx.x, lane = threadIdx.x;
-    const int64_t sj = LDSIMG ? 1 : Pn, sp = LDSIMG ? Wmax + 1 : 1;
+    const int64_t sj = Pn, sp = 1;
     T *seg = aux + (int64_t)p * sp;
     const int chunk = (Wmax + 63) / 64;
     const int j0 = lane * chunk, j1 = min(j0 + chunk, Wmax);
@@ -707,10 +800,10 @@ waypoint_cumsum_kernel(int Wmax, int Pn, T *__restrict__ aux)
 }
 
 template <typename T>
-size_t waypoint_aux_len(int P, int Wmax, bool ldsimg)
+size_t waypoint_aux_len(int P, int Wmax)
 {
     const size_t nb = (size_t)(Wmax + kWpBlock - 1) / kWpBlock;
-    return (size_t)(Wmax + (ldsimg ? 1 : 0)) * P + nb * 4 * P;
+    return (size_t)Wmax * P + nb * 4 * P;
 }
 
 // Closed-loop rollout: the sub-step loop of drive.py:114-151 without the planner.  Every
@@ -734,27 +827,17 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
 {
     if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // LDS image: P tables of (x, y) pairs, then P tables of segment lengths; each table is
-    // padded by one entry so that the tables of different paths start on different banks
-    // (lanes of one wave follow different paths and read the same waypoint index together)
-    const int wstride = Wmax + 1;
-    const int nbmax = (Wmax + kWpBlock - 1) / kWpBlock;
-    T *lds_wp = reinterpret_cast<T *>(smem_raw);
-    T *lds_seg = lds_wp + (int64_t)Pn * wstride * 2;
-    T *lds_bnd = lds_seg + (int64_t)Pn * wstride;      // [P][nbmax][4] bounding circles of 32-waypoint blocks
-    if (WPLDS) {
-        // (x, y) pairs row by row (the LDS rows are one entry longer than the table's), then the
-        // segment lengths and bounding circles, which waypoint_aux_kernel<T, true> computed once for
-        // all workgroups in exactly this layout: two flat copies
-        for (int p = 0; p < Pn; ++p) {
-            const T *src = wp + (int64_t)p * Wmax * 2;
-            T *dst = lds_wp + (int64_t)p * wstride * 2;
-            for (int j = threadIdx.x; j < 2 * Wmax; j += kBlock) dst[j] = src[j];
-        }
-        const int naux = Pn * wstride + Pn * nbmax * 4;          // lds_seg and lds_bnd are adjacent
-        for (int i = threadIdx.x; i < naux; i += kBlock) lds_seg[i] = aux[i];
-        __syncthreads();
-    }
+    // LDS image (ClosedLoopLds, vdyn_controls.hpp): x rows, y rows (padded to whole 8-waypoint sub-blocks, 16-byte
+    // aligned, rows of different paths 4 banks apart: lanes of one wave follow different paths and read the same
+    // waypoint index together), segment lengths / cumulative arcs, one bounding circle per 32 and per 8 waypoints
+    const ClosedLoopLds<T> LL(Pn, Wmax);
+    const int nbmax = LL.nb;
+    T *lds = reinterpret_cast<T *>(smem_raw);
+    // tables in LDS: every workgroup builds the whole image for itself, from the caller's tables alone
+    PhaseClock pc0;
+    VDYN_PHASE_START(pc0);
+    if (WPLDS) build_closed_loop_lds<T, kBlock>(lds, LL, wp, Wmax, wcount, Pn);
+    VDYN_PHASE_LAP(pc0, 10);     // LDS image
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = gid < n;
     const int64_t r = active ? gid : n - 1;
@@ -773,11 +856,17 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     c.cte = T(0);
 
     const int pid = min(max(path_id[r], 0), Pn - 1);
-    Waypoints<T> w;
-    w.base = WPLDS ? lds_wp + (int64_t)pid * wstride * 2 : wp + (int64_t)pid * Wmax * 2;
-    // not in LDS: the transposed global tables of waypoint_aux_kernel<T, false> (nullptr: plain full scan)
-    w.seg = WPLDS ? lds_seg + (int64_t)pid * wstride : (aux != nullptr ? aux + pid : nullptr);
-    w.bounds = WPLDS ? lds_bnd + (int64_t)pid * nbmax * 4 : (aux != nullptr ? aux + (int64_t)Wmax * Pn + pid : nullptr);
+    Waypoints<T, WPLDS> w;
+    w.base = WPLDS ? lds + LL.xs + (int64_t)pid * LL.ws : wp + (int64_t)pid * Wmax * 2;
+    w.yo = WPLDS ? (int)(LL.ys - LL.xs) : 1;
+    // not in LDS: the transposed global tables of waypoint_aux_kernel<T> (nullptr: plain full scan)
+    w.seg = WPLDS ? lds + LL.seg + (int64_t)pid * LL.segs : (aux != nullptr ? aux + pid : nullptr);
+    w.bounds = WPLDS ? lds + LL.bnd + (int64_t)pid * LL.brs : (aux != nullptr ? aux + (int64_t)Wmax * Pn + pid : nullptr);
+    w.sub = WPLDS ? lds + LL.sub + (int64_t)pid * LL.srs : nullptr;
+    w.bo = Pn * LL.brs;
+    w.so = Pn * LL.srs;
+    w.nbu = LL.nbu;
+    w.nsbu = LL.nsbu;
     w.ss = w.bs = WPLDS ? 1 : Pn;
     w.W = min(max(wcount[pid], 1), Wmax);
     StepEngine<T> eng;
@@ -785,26 +874,35 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
 
     int until_update = (ctrl_every - phase % ctrl_every) % ctrl_every;   // steps until (phase + t) % ctrl_every == 0
     int t = 0;
+    VDYN_PHASE_LAP(pc0, 11);     // state loads, engine set-up
     if (!DATALOG && !LOG) {
         // nothing is written per sub-step: between two controller updates the commands are held (drive.py:128), so the
         // sub-steps in between run in a loop of their own, two per trip (see rollout_kernel)
+        PhaseClock pc;
+        VDYN_PHASE_START(pc);
         while (t < H) {
             if (until_update == 0) {
+                VDYN_PHASE_LAP(pc, 7);      // held sub-steps
                 T steer_raw, s[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) s[i] = X.get(i);
                 controller_update<T>(G, w, s, h, c, steer_raw);
                 until_update = ctrl_every;
+                VDYN_PHASE_LAP(pc, 6);      // whole controller update
             }
             const int run = min(until_update, H - t);
             const T delta[4] = {c.delta, c.delta, T(0), T(0)};
             const T tq[4] = {c.tau, c.tau, c.tau, c.tau};
+            // the steering angle is held until the next update: its (sin, cos) once, by the function the step itself
+            // would call (the same values, PRE = 1), instead of at every sub-step
+            T sd0, cd0;
+            eng.steer_sincos(c.delta, sd0, cd0);
             int j = 0;
             for (; j + 1 < run; j += 2) {
-                eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
-                eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+                eng.template advance_state<true, CS, 1>(P, X, delta, tq, P.mu, h, sd0, cd0);
+                eng.template advance_state<true, CS, 1>(P, X, delta, tq, P.mu, h, sd0, cd0);
             }
-            if (j < run) eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+            if (j < run) eng.template advance_state<true, CS, 1>(P, X, delta, tq, P.mu, h, sd0, cd0);
             t += run;
             until_update -= run;
         }
@@ -1630,13 +1728,34 @@ hipError_t launch_planar_model(const VdynParams &p, int64_t n, const T *state, c
     return hipGetLastError();
 }
 
+// Candidates per wave of mpc_argmin_lanes_kernel: the grid should be about `target` waves (two per SIMD in fp32, one
+// in fp64: the register budget of the step), but a wave keeps at least 2 candidates when there are that many.
+template <typename T>
+static int mpc_chunk(int E, int C)
+{
+    const int64_t target = sizeof(T) == 4 ? 2048 : 1024, groups = (E + 63) / 64;
+    const int64_t kc = (groups * C + target - 1) / target;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kc, C));
+}
+
+// Device scratch of launch_mpc_argmin: the candidate table with (sin, cos) per entry, then the per-chunk partial
+// minima (cost, index) [nchunks][E].
+template <typename T>
+size_t mpc_scratch_bytes(int E, int C, int H)
+{
+    const size_t nchunks = ((size_t)C + mpc_chunk<T>(E, C) - 1) / mpc_chunk<T>(E, C);
+    const size_t tab = ((sizeof(T) * 4 * (size_t)H * C + 255) / 256) * 256;
+    return tab + nchunks * (size_t)E * (sizeof(T) + sizeof(int)) + 256;
+}
+
 template <typename T>
 hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *ego, const T *cand,
                              const T *goal, double dt, double w_delta, T *best_cost, int *best_idx,
-                             T *cost_all, T *cand4, hipStream_t st)
+                             T *cost_all, void *scratch, hipStream_t st)
 {
     if (E <= 0) return hipSuccess;
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
+    T *cand4 = static_cast<T *>(scratch);
     if (H > 0) {
         const int64_t n = (int64_t)H * C;
         hipLaunchKernelGGL((mpc_prepare_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, P,
@@ -1644,14 +1763,21 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
     }
-    int block = ((C + 63) / 64) * 64;
-    block = std::max(64, std::min(block, mpc_block_max<T>()));
+    const int KC = mpc_chunk<T>(E, C), nchunks = (C + KC - 1) / KC, groups = (E + 63) / 64;
+    const size_t tab = ((sizeof(T) * 4 * (size_t)H * C + 255) / 256) * 256;
+    T *part_cost = reinterpret_cast<T *>(static_cast<char *>(scratch) + tab);
+    int *part_idx = reinterpret_cast<int *>(part_cost + (size_t)nchunks * E);
+    const unsigned grid = (unsigned)((int64_t)groups * nchunks);
     if (lane_cs<T>(p))
-        hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
-                           C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+        hipLaunchKernelGGL((mpc_argmin_lanes_kernel<T, true>), dim3(grid), dim3(64), 0, st, P, E, C, H, KC, ego, cand4,
+                           goal, (T)dt, (T)w_delta, part_cost, part_idx, cost_all);
     else
-        hipLaunchKernelGGL((mpc_argmin_kernel<T, false>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
-                           C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+        hipLaunchKernelGGL((mpc_argmin_lanes_kernel<T, false>), dim3(grid), dim3(64), 0, st, P, E, C, H, KC, ego, cand4,
+                           goal, (T)dt, (T)w_delta, part_cost, part_idx, cost_all);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return e_;
+    hipLaunchKernelGGL((mpc_reduce_kernel<T>), dim3((unsigned)((E + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, E, nchunks,
+                       part_cost, part_idx, best_cost, best_idx);
     return hipGetLastError();
 }
 
@@ -1678,26 +1804,21 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     const DevParams<T> P = make_dev_params<T>(p, nullptr);
     const CtrlGains<T> G = make_gains<T>(g);
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
-    // padded (x, y) pairs + segment lengths + one bounding circle per 32 waypoints
-    const size_t wp_bytes = ((size_t)a.P * (a.Wmax + 1) * 3 + (size_t)a.P * ((a.Wmax + kWpBlock - 1) / kWpBlock) * 4) * sizeof(T);
+    // x / y rows + segment lengths + one bounding circle per 32 and per 8 waypoints (ClosedLoopLds)
+    const size_t wp_bytes = ClosedLoopLds<T>(a.P, a.Wmax).bytes();
     // gfx950 has 160 KiB of LDS per CU; a workgroup may take all of it (one workgroup per
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
     const bool lds = wp_bytes <= kClosedLoopLdsBudget;
     const bool cs = lane_cs<T>(p);
-    if (a.aux == nullptr && lds) return hipErrorInvalidValue;       // the LDS image is not optional
-    if (a.aux != nullptr) {
+    // tables in LDS: the kernel builds its whole image itself; otherwise the transposed tables in `aux`
+    if (a.aux != nullptr && !lds) {
         const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
-        if (lds)
-            hipLaunchKernelGGL((waypoint_aux_kernel<T, true>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp,
-                               a.Wmax, a.wcount, a.P, a.aux);
-        else
-            hipLaunchKernelGGL((waypoint_aux_kernel<T, false>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp,
-                               a.Wmax, a.wcount, a.P, a.aux);
+        hipLaunchKernelGGL((waypoint_aux_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp,
+                           a.Wmax, a.wcount, a.P, a.aux);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
         if (sizeof(T) == 4) {                                   // fp32: cumulative arc length instead of segment lengths
-            if (lds) hipLaunchKernelGGL((waypoint_cumsum_kernel<T, true>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
-            else hipLaunchKernelGGL((waypoint_cumsum_kernel<T, false>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
+            hipLaunchKernelGGL((waypoint_cumsum_kernel<T>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
             e_ = hipGetLastError();
             if (e_ != hipSuccess) return e_;
         }
@@ -1735,9 +1856,10 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
 template <typename T>
 size_t closed_loop_aux_bytes(int P, int Wmax, bool update_only)
 {
-    const size_t wp_bytes = ((size_t)P * (Wmax + 1) * 3 + (size_t)P * ((Wmax + kWpBlock - 1) / kWpBlock) * 4) * sizeof(T);
-    if (update_only) return Wmax < 4 * kWpBlock ? 0 : waypoint_aux_len<T>(P, Wmax, false) * sizeof(T);
-    return waypoint_aux_len<T>(P, Wmax, wp_bytes <= kClosedLoopLdsBudget) * sizeof(T);
+    const size_t wp_bytes = ClosedLoopLds<T>(P, Wmax).bytes();
+    if (update_only) return Wmax < 4 * kWpBlock ? 0 : waypoint_aux_len<T>(P, Wmax) * sizeof(T);
+    if (wp_bytes <= kClosedLoopLdsBudget) return 0;            // the kernel builds its LDS image from the tables alone
+    return waypoint_aux_len<T>(P, Wmax) * sizeof(T);
 }
 
 template <typename T>
@@ -1748,12 +1870,12 @@ hipError_t launch_controller_update(const VdynCtrlGains &g, const ClosedLoopArgs
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
     if (a.aux != nullptr) {
         const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
-        hipLaunchKernelGGL((waypoint_aux_kernel<T, false>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
+        hipLaunchKernelGGL((waypoint_aux_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, st, a.wp, a.Wmax,
                            a.wcount, a.P, a.aux);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
         if (sizeof(T) == 4) {
-            hipLaunchKernelGGL((waypoint_cumsum_kernel<T, false>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
+            hipLaunchKernelGGL((waypoint_cumsum_kernel<T>), dim3((unsigned)a.P), dim3(64), 0, st, a.Wmax, a.P, a.aux);
             e_ = hipGetLastError();
             if (e_ != hipSuccess) return e_;
         }
@@ -1815,7 +1937,8 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     template hipError_t launch_planar_model<T>(const VdynParams &, int64_t, const T *, const T *,    \
                                                const T *, T *, T *, T *, T *, hipStream_t);          \
     template hipError_t launch_mpc_argmin<T>(const VdynParams &, int, int, int, const T *, const T *, \
-                                             const T *, double, double, T *, int *, T *, T *, hipStream_t); \
+                                             const T *, double, double, T *, int *, T *, void *, hipStream_t); \
+    template size_t mpc_scratch_bytes<T>(int, int, int);                                             \
     template hipError_t launch_closed_loop<T>(const VdynParams &, const VdynCtrlGains &,             \
                                               const ClosedLoopArgs<T> &, hipStream_t);               \
     template hipError_t launch_controller_update<T>(const VdynCtrlGains &, const ClosedLoopArgs<T> &, hipStream_t); \

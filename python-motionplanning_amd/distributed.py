@@ -71,6 +71,7 @@ class AllGatherExchange:
     (bench.py queues the next rollout in between, so exchange k overlaps rollout k + 1)."""
 
     kind = "all_gather_into_tensor"
+    fallback_reason = None
 
     def __init__(self, sh: ShardedRollout, rows: int, like: torch.Tensor):
         self.sh, self.rows = sh, int(rows)
@@ -135,42 +136,98 @@ class PeerExchange:
     2-process test on one GPU exercises handles, slots and ordering."""
 
     kind = "peer_copies"
+    fallback_reason = None
 
     def __init__(self, sh: ShardedRollout, rows: int, like: torch.Tensor, handle):
+        x, why = self._build(self, sh, rows, like, handle)
+        if x is None:
+            raise RuntimeError("peer-copy exchange unavailable: " + why)
+
+    @classmethod
+    def try_create(cls, sh: ShardedRollout, rows: int, like: torch.Tensor, handle, self_test=True):
+        """(exchange, None), or (None, reason) when ANY rank could not set it up or the self test -- one real
+        exchange of a known pattern, checked on every rank -- failed.  Collective: every rank calls it, every rank
+        gets the same verdict, and no rank is left waiting in a collective for one that gave up (local failures are
+        recorded and agreed on with an all-reduce before the next collective step)."""
+        obj = cls.__new__(cls)
+        x, why = cls._build(obj, sh, rows, like, handle)
+        if x is None:
+            return None, why
+        if self_test:
+            ok = True
+            try:
+                src = like.new_full((x.rows, sh.n_local), float(sh.rank + 1))
+                x.start(src)
+                got = x.result()
+                for r, (lo, hi) in enumerate(sh.bounds):
+                    ok = ok and bool((got[:, lo:hi] == float(r + 1)).all())
+            except Exception as e:                      # noqa: BLE001 -- any failure means "do not use"
+                ok, why = False, f"self test raised {e!r}"
+            if not x._agree(ok):
+                x.close()
+                return None, why or "self test: a rank did not receive every rank's block"
+        return x, None
+
+    def _agree(self, ok: bool) -> bool:
+        """Logical AND of `ok` over the ranks (all-reduce MIN on the group's own backend)."""
+        if not (dist.is_initialized() and self.sh.world > 1):
+            return bool(ok)
+        on_gpu = "nccl" in str(dist.get_backend(self.sh.group))
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.sh.group)
+        return bool(int(t.item()) == 1)
+
+    @staticmethod
+    def _build(self, sh, rows, like, handle):
         import ctypes as C
         from . import _lib
         self._C, self._lib = C, _lib
         self.sh, self.rows, self.h = sh, int(rows), handle
+        self._device = like.device
         self.itemsize = like.element_size()
         self.block, total, self.offsets = slot_layout(sh.world, rows, sh.n_pad, self.itemsize)
+        self._own, self._peers, self._pending, self.recv = None, [], None, None
+        why = None
         own, ipc = C.c_void_p(), _lib.VdynIpcHandle()
-        handle.call("vdyn_xchg_alloc", total, C.byref(own), C.byref(ipc))
-        self._own = own.value
-        typestr = {4: "<f4", 8: "<f8"}[self.itemsize]
-        self.recv = torch.as_tensor(_DeviceBuffer(self._own, (sh.world * self.rows, sh.n_pad), typestr),
-                                    device=like.device)
-        self.recv.zero_()
-        self.send = like.new_zeros((self.rows, sh.n_pad)) if sh.n_local != sh.n_pad else None
-        # the zero fill must have RUN before a peer can learn this buffer's handle: its first push could otherwise
-        # land before the fill and be wiped by it
-        torch.cuda.synchronize(like.device)
-        # every rank learns every rank's handle; its own buffer is used through the local pointer
+        try:
+            handle.call("vdyn_xchg_alloc", total, C.byref(own), C.byref(ipc))
+            self._own = own.value
+            typestr = {4: "<f4", 8: "<f8"}[self.itemsize]
+            self.recv = torch.as_tensor(_DeviceBuffer(self._own, (sh.world * self.rows, sh.n_pad), typestr),
+                                        device=like.device)
+            self.recv.zero_()
+            self.send = like.new_zeros((self.rows, sh.n_pad)) if sh.n_local != sh.n_pad else None
+            # the zero fill must have RUN before a peer can learn this buffer's handle: its first push could
+            # otherwise land before the fill and be wiped by it
+            torch.cuda.synchronize(like.device)
+        except Exception as e:                          # noqa: BLE001
+            why = f"rank {sh.rank}: allocating / exporting the slot buffer failed: {e!r}"
+        # every rank learns every rank's handle (None from a rank that failed); its own buffer is used through the
+        # local pointer
         blobs = [None] * sh.world
         if sh.world > 1:
-            dist.all_gather_object(blobs, bytes(ipc.bytes), group=sh.group)
-        self._peers = []
+            dist.all_gather_object(blobs, bytes(ipc.bytes) if why is None else None, group=sh.group)
         ptrs = (C.c_void_p * sh.world)()
-        for r in range(sh.world):
-            if r == sh.rank:
-                ptrs[r] = self._own
-                continue
-            peer, hd = C.c_void_p(), _lib.VdynIpcHandle()
-            C.memmove(hd.bytes, blobs[r], 64)
-            handle.call("vdyn_xchg_open", C.byref(hd), C.byref(peer))
-            self._peers.append(peer.value)
-            ptrs[r] = peer.value
+        if why is None and any(bl is None for r, bl in enumerate(blobs) if r != sh.rank):
+            why = "a peer could not export its slot buffer"
+        if why is None:
+            try:
+                for r in range(sh.world):
+                    if r == sh.rank:
+                        ptrs[r] = self._own
+                        continue
+                    peer, hd = C.c_void_p(), _lib.VdynIpcHandle()
+                    C.memmove(hd.bytes, blobs[r], 64)
+                    handle.call("vdyn_xchg_open", C.byref(hd), C.byref(peer))
+                    self._peers.append(peer.value)
+                    ptrs[r] = peer.value
+            except Exception as e:                      # noqa: BLE001
+                why = f"rank {sh.rank}: opening a peer's slot buffer failed: {e!r}"
         self._dst = ptrs
-        self._pending = None
+        if not self._agree(why is None):
+            self.close()
+            return None, why or "another rank could not set up its peer buffers"
+        return self, None
 
     def start(self, term_local: torch.Tensor):
         assert self._pending is None, "wait() for the previous exchange first"
@@ -204,7 +261,8 @@ class PeerExchange:
         return out
 
     def close(self):
-        if self._own is None:
+        """Collective (a barrier before the buffers go)."""
+        if self._own is None and not self._peers:
             return
         self.wait()
         if dist.is_initialized() and self.sh.world > 1:
@@ -213,11 +271,21 @@ class PeerExchange:
             self.h.call("vdyn_xchg_close", self._C.c_void_p(p))
         self._peers = []
         self.recv = None
-        self.h.call("vdyn_xchg_free", self._C.c_void_p(self._own))
+        if self._own is not None:
+            self.h.call("vdyn_xchg_free", self._C.c_void_p(self._own))
         self._own = None
 
 
 def make_exchange(kind: str, sh: ShardedRollout, rows: int, like: torch.Tensor, handle=None):
+    """`auto`: the peer-copy exchange when every rank can set it up AND one real exchange of a known pattern
+    arrives intact on every rank (PeerExchange.try_create), the RCCL all-gather otherwise; the returned object says
+    which (`kind`) and, after a fallback, why (`fallback_reason`)."""
+    if kind == "auto":
+        x, why = (None, "no library handle") if handle is None else PeerExchange.try_create(sh, rows, like, handle)
+        if x is None:
+            x = AllGatherExchange(sh, rows, like)
+            x.fallback_reason = why
+        return x
     if kind == "rccl":
         return AllGatherExchange(sh, rows, like)
     if kind == "p2p":

@@ -25,6 +25,7 @@ Sets:
      lateral goals, the steering sequences they imply, terminal states from planar_model_RK4
   G13 planning cycles in which the reference drops unreachable spirals (plan_paths validity), incl. "every
      surviving path collides" and "no spiral survives": collision flags and best index over the survivors
+  G14 the two global paths of configs[0] (world.path; the csv path of env.py:16-20) + the world's obstacle points
   G9 closed-loop controller logs of the same 3-frame Car.drive run as G4 (world.path):
      the waypoint lists the planner handed to the Stanley controller, every
      stanley_control / long_control call (inputs -> outputs) and the steering filter
@@ -667,7 +668,29 @@ def g13():
         weight=np.float64(drive.PATH_SELECT_WEIGHT))
 
 
+def g14():
+    """The two global paths of BASELINE configs[0] -- world.path (animate.py:27) and the path the reference builds
+    from data/waypoints.csv (env.py:16-20, Path.create_fromcsv: cubic-spline resampling) -- with the world's obstacle
+    points, and the vehicle state the reference's Car.drive reaches after 3 frames on each (= the last row of G4):
+    inputs for bench.py's config0 line and for the mirror Car on the csv path."""
+    import scipy.integrate
+    if not hasattr(scipy.integrate, "cumtrapz"):
+        scipy.integrate.cumtrapz = scipy.integrate.cumulative_trapezoid
+    from libs.utils.env import world, Path
+    pth = Path([0, 1, 2, 3], [0, 0, 0, 0])
+    pth.create_fromcsv(os.path.join(REF, "data", "waypoints.csv"))
+    out = {"world_px": np.asarray(world.path.px, float), "world_py": np.asarray(world.path.py, float),
+           "world_pyaw": np.asarray(world.path.pyaw, float), "csv_px": np.asarray(pth.px, float),
+           "csv_py": np.asarray(pth.py, float), "csv_pyaw": np.asarray(pth.pyaw, float),
+           "obstacle_xy": np.asarray(world.obstacle_xy, float)}
+    for tag in ("world", "waypoints"):
+        g4 = np.load(os.path.join(HERE, f"g4_closed_loop_{tag}.npz"))
+        out[f"{tag}_state_after_3_frames"] = g4["state_update"][-1]
+    np.savez_compressed(os.path.join(HERE, "g14_global_paths.npz"), **out)
+    print("G14", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_g6", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

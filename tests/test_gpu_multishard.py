@@ -90,7 +90,7 @@ def test_peer_copy_exchange_two_processes_one_gpu(tmp_path, gpu_vm, workloads, n
         assert got.shape == single.shape and np.array_equal(got, single)
 
 
-@pytest.mark.parametrize("mode,exchange", [("weak", "p2p"), ("strong", "p2p"), ("weak", "rccl")])
+@pytest.mark.parametrize("mode,exchange", [("weak", "p2p"), ("strong", "p2p"), ("weak", "rccl"), ("weak", "auto")])
 def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode, exchange):
     """bench.py's WHOLE N > 1 path on hardware, as far as one GPU allows: `python bench.py --gpus 2` starts its two
     ranks itself, both ranks integrate their whole-ego shard with the HIP kernel on GPU 0, the terminal blocks travel
@@ -119,8 +119,9 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
     n_total = 2 * per_gpu if mode == "weak" else per_gpu
     assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["rollouts_total"] == n_total and out["scaling"] == mode
     assert out["shards"] == [list(workloads.shard_egos(n_total, 2, r)) for r in range(2)]
-    assert out["exchange"] == {"kind": "peer_copies" if exchange == "p2p" else "all_gather_into_tensor", "overlapped": True,
-                               "bytes_per_rank": 12 * (out["shards"][0][1]) * 4, "verified": True}
+    assert out["exchange"] == {"kind": "peer_copies" if exchange in ("p2p", "auto") else "all_gather_into_tensor",
+                               "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4, "verified": True,
+                               "requested": exchange, "fallback_reason": None}
     assert out["value"] > 0 and out["roofline"]["bound"] == "valu" and "cpu_baseline" not in out
     s0, tab, pid = workloads.config3(n_total, 50, np.float32)
     dev = torch.device("cuda:0")
@@ -130,7 +131,7 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
         assert np.array_equal(np.load(tmp_path / f"gathered_rank{r}.npy"), single), "what every rank holds == the single launch"
 
 
-@pytest.mark.parametrize("exchange,overlap", [("rccl", True), ("rccl", False), ("p2p", True)])
+@pytest.mark.parametrize("exchange,overlap", [("rccl", True), ("rccl", False), ("p2p", True), ("auto", True)])
 def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
     """The DEFAULT multi-GPU path of bench.py as an 8-GPU run executes it -- torch.distributed on the `nccl` backend
     (= RCCL) with `device_id` set, `all_gather_into_tensor(async_op=True)` overlapped with the next launch
@@ -155,6 +156,7 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
     assert out["n_gpus"] == 1 and out["world_seen"] == 1 and out["rollouts_total"] == 65536
     assert out["dist_backend"] == "nccl"
     assert out["exchange"] == {"kind": "all_gather_into_tensor" if exchange == "rccl" else "peer_copies",
-                               "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True}
+                               "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True,
+                               "requested": exchange, "fallback_reason": None}
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
     assert out["roofline"]["bound"] == "valu" and out["shards"] == [[0, 65536]]
