@@ -70,7 +70,11 @@ def build(case, pkg, torch, dev):
         cl = [torch.from_numpy(a).to(dev) for a in W.closed_loop_config(n, dtype=np.float32)]
         dl = case.endswith("datalog")
         Wp, P = 1024, 7
-        lds = (P * (Wp + 1) * 3 + P * ((Wp + 31) // 32) * 4) * 4
+        # ClosedLoopLds (csrc/vdyn_controls.hpp): x / y rows, cumulative arcs, circle rows per 32 and per 8 waypoints
+        nb, nsb = (Wp + 31) // 32, (Wp + 7) // 8
+        ws, segs = nsb * 8 + 4, (Wp + 3) // 4 * 4 + 4
+        brs, srs = (nb + 15) // 16 * 16 + 4, (nsb + 15) // 16 * 16 + 20
+        lds = (2 * P * ws + P * segs + 3 * P * (brs + srs)) * 4
         return (lambda: vm.closed_loop(cl[0], cl[1], cl[2], H, wcount=cl[3], path_id=cl[4], datalog=dl)), dict(
             kernel=f"closed_loop_kernel<float, true, true, {'true' if dl else 'false'}", steps_per_lane=H,
             vehicle_steps=n * H, algo_bytes=(24 + 12) * 4 * n + 4 * n + cl[2].numel() * 4 + (180 * n * H if dl else 0),

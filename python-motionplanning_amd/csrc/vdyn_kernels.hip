@@ -671,17 +671,22 @@ mpc_argmin_lanes_kernel(DevParams<T> P, int E, int C, int H, int KC, const T *__
 }
 
 // part [nchunks][E] -> (best_cost, best_idx)[E]: chunks in ascending order (= ascending candidate index), strict '<'.
+// A workgroup = 64 egos x 4 waves; wave w scans its quarter of the chunks with sixteen loads in flight (a single scan
+// of 128 chunks, eight at a time, took 9 us: sixteen dependent L2 round trips), the quarters meet in LDS in wave order.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 mpc_reduce_kernel(int E, int nchunks, const T *__restrict__ part_cost, const int *__restrict__ part_idx,
                   T *__restrict__ best_cost, int *__restrict__ best_idx)
 {
-    const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (e >= E) return;
-    constexpr int kNone = 0x7fffffff, kFly = 8;
+    __shared__ T s_cost[kBlock / 64 - 1][64];
+    __shared__ int s_idx[kBlock / 64 - 1][64];
+    constexpr int kNone = 0x7fffffff, kFly = 16, kWaves = kBlock / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e_raw = (int)blockIdx.x * 64 + lane, e = min(e_raw, E - 1);
+    const int per = (nchunks + kWaves - 1) / kWaves, k_lo = wave * per, k_hi = min(k_lo + per, nchunks);
     T bc = T(INFINITY);
     int bi = kNone;
-    for (int k0 = 0; k0 < nchunks; k0 += kFly) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += kFly) {
         T pc[kFly];
         int pi[kFly];
 #pragma unroll
@@ -692,10 +697,17 @@ mpc_reduce_kernel(int E, int nchunks, const T *__restrict__ part_cost, const int
         }
 #pragma unroll
         for (int k = 0; k < kFly; ++k)
-            if (k0 + k < nchunks && pc[k] < bc) { bc = pc[k]; bi = pi[k]; }
+            if (k0 + k < k_hi && pc[k] < bc) { bc = pc[k]; bi = pi[k]; }
     }
-    best_cost[e] = bc;
-    best_idx[e] = bi == kNone ? -1 : bi;
+    if (wave > 0) { s_cost[wave - 1][lane] = bc; s_idx[wave - 1][lane] = bi; }
+    __syncthreads();
+    if (wave == 0 && e_raw < E) {
+#pragma unroll
+        for (int w = 0; w < kWaves - 1; ++w)
+            if (s_cost[w][lane] < bc) { bc = s_cost[w][lane]; bi = s_idx[w][lane]; }
+        best_cost[e] = bc;
+        best_idx[e] = bi == kNone ? -1 : bi;
+    }
 }
 
 // Auxiliary waypoint tables for the controllers when the P tables do not fit LDS: segment lengths
@@ -1764,6 +1776,21 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
         if (e_ != hipSuccess) return e_;
     }
     const int KC = mpc_chunk<T>(E, C), nchunks = (C + KC - 1) / KC, groups = (E + 63) / 64;
+    // Which mapping: egos on the lanes needs whole waves of egos and enough (ego group, chunk) pairs to fill the chip;
+    // below that a workgroup per ego wastes no lanes and needs no second kernel.  Both give the same bits
+    // (tools/ubench/mpc_harness.hip); configs[4]: 0.306 against 0.311 ms per call.
+    const bool lanes = E >= 512 && (int64_t)groups * C >= 1024;
+    if (!lanes) {
+        int block = ((C + 63) / 64) * 64;
+        block = std::max(64, std::min(block, mpc_block_max<T>()));
+        if (lane_cs<T>(p))
+            hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
+                               C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+        else
+            hipLaunchKernelGGL((mpc_argmin_kernel<T, false>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
+                               C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+        return hipGetLastError();
+    }
     const size_t tab = ((sizeof(T) * 4 * (size_t)H * C + 255) / 256) * 256;
     T *part_cost = reinterpret_cast<T *>(static_cast<char *>(scratch) + tab);
     int *part_idx = reinterpret_cast<int *>(part_cost + (size_t)nchunks * E);
@@ -1776,7 +1803,7 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
                            goal, (T)dt, (T)w_delta, part_cost, part_idx, cost_all);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) return e_;
-    hipLaunchKernelGGL((mpc_reduce_kernel<T>), dim3((unsigned)((E + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, E, nchunks,
+    hipLaunchKernelGGL((mpc_reduce_kernel<T>), dim3((unsigned)groups), dim3(kBlock), 0, st, E, nchunks,
                        part_cost, part_idx, best_cost, best_idx);
     return hipGetLastError();
 }

@@ -346,6 +346,41 @@ def test_mpc_ties_and_disqualification(gpu_vm, workloads):
     assert bi[1] == -1 and np.isinf(bc[1]) and (bi[[0, 2, 3]] >= 0).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_mpc_egos_on_lanes_mapping_ties_nan_ragged(gpu_vm, oracle, workloads, dtype):
+    """The selection kernel with the egos on the lanes (E >= 512: a wave = 64 egos x a chunk of candidates, partial
+    minima per chunk, mpc_reduce_kernel) on sizes that divide nothing -- 517 egos (a ragged last wave), 260 candidates
+    in chunks of 2 / 3, 9 steps (the odd last step of the two-step loop) -- with every candidate present twice (ties:
+    the lower index must win across chunk boundaries) and egos whose costs are all non-finite (index -1)."""
+    E, C, H, dt = 517, 260, 9, 2e-3
+    ego, _, goal = workloads.config5(E, C, 10, np.float64)
+    rng = np.random.default_rng(77)
+    cand = np.empty((H, 2, C))
+    cand[:, 0] = np.clip(rng.normal(0.0, 0.05, (H, C)), -0.5236, 0.5236)
+    cand[:, 1] = 100.0 + rng.normal(0.0, 200.0, (H, C))
+    cand[:, :, C // 2:] = cand[:, :, :C // 2]                  # candidate c + 130 == candidate c
+    ego[0, 5] = 0.0
+    ego[2, 5] = 0.0                                            # vx = 0 -> division by zero -> every cost non-finite
+    ego[3:7, 5] = 0.0
+    vm = gpu_vm(dt)
+    a = [x.astype(dtype) for x in (ego, cand, goal)]
+    bc, bi, cost = vm.mpc_argmin(*a, w_delta=workloads.MPC_W_DELTA, return_costs=True)
+    assert cost.shape == (E, C) and bi[5] == -1 and np.isinf(bc[5])
+    ok = np.arange(E) != 5
+    assert np.isfinite(cost[ok]).all() and (bi[ok] >= 0).all() and (bi[ok] < C // 2).all(), "lower index wins every tie"
+    assert np.array_equal(bi[ok], cost[ok].argmin(axis=1)) and np.array_equal(bc[ok], cost[ok].min(axis=1))
+    assert np.array_equal(cost[ok, :C // 2], cost[ok, C // 2:]), "a candidate's cost does not depend on its chunk"
+    obc, obi, ocost = oracle.mpc_argmin(oracle.default_params(), ego, cand, goal, dt, workloads.MPC_W_DELTA,
+                                        nthreads=oracle.max_threads(), return_costs=True)
+    tol = 1e-9 if dtype == np.float64 else 1e-3
+    assert np.abs(cost[ok] - ocost[ok]).max() <= tol
+    if dtype == np.float64:
+        assert np.array_equal(bi[ok], obi[ok])
+    # without the cost matrix the result is the same
+    bc2, bi2 = vm.mpc_argmin(*a, w_delta=workloads.MPC_W_DELTA)
+    assert np.array_equal(bi2, bi) and np.array_equal(bc2[ok], bc[ok])
+
+
 def test_nonfinite_propagates_only_in_its_lane(gpu_vm, workloads):
     s0, ctrl = workloads.config2(8, 20)
     clean = gpu_vm(1e-3).rollout(s0, ctrl)
