@@ -36,10 +36,14 @@ namespace vdyn {
 // (c in (0, 1]) -- no argument reduction, no branch, no x > 1 case.  The coefficients depend on C, which belongs to
 // the handle: the host fits them when it builds DevParams (make_dev_params, vdyn_kernels.hip) and checks the fp32
 // Horner evaluation against double; W[i][wheel], highest degree first.
-// fp64 (the trimmed scalar step below and the wheel-parallel one): degree 18, and ONE set of coefficients -- the
-// four wheels must share C (true of the reference's parameters, vehicle_model.py:44-45); nineteen doubles per
-// wheel would not fit the scalar registers a wave-uniform constant lives in.  A handle that does not qualify
-// (different C per wheel, or a fit that fails its check) takes the general atan -> sine chain (lane_cs).
+// fp64 (the trimmed scalar step below and the wheel-parallel one): degree 18, W[i][wheel] as well.  Nineteen doubles
+// per wheel fit neither the scalar registers a wave-uniform constant lives in (round 2 kept ONE set, pinned in 38
+// VGPRs, and sent handles whose wheels differ in C to the general chain at half the speed) nor, four times over, the
+// vector file.  So: wheels that share C (the reference's) -> that one set pinned in VGPRs as in round 2 (pin_tire_fit);
+// wheels that differ -> the rollout kernel stages the table in LDS once per workgroup and the step reads it back as
+// it goes (fit_horner4_lds: 152 more instructions per step, 0.56 against 0.42 ms on configs[1], against 0.87 for the
+// general chain); the wheel-parallel kernel keeps its lane's own wheel's column in registers either way.
+// A handle whose fits fail their check takes the general atan -> sine chain (lane_cs).
 constexpr int kTireFitDeg = 8;
 constexpr int kTireFitDeg64 = 18;
 template <typename T> struct TireFit;
@@ -47,13 +51,13 @@ template <> struct TireFit<float> {
     float W[kTireFitDeg + 1][4];
 };
 template <> struct TireFit<double> {
-    double W[kTireFitDeg64 + 1];
+    double W[kTireFitDeg64 + 1][4];
 };
-__device__ __forceinline__ const double *tire_fit64(const TireFit<double> &f) { return f.W; }
-__device__ __forceinline__ const float *tire_fit64(const TireFit<float> &) { return nullptr; }
 
+// Everything else the step needs of a vehicle.  DevParams = the fits, then this: kernels take a DevParams by value
+// as their FIRST argument, so the fits sit at offset 0 of the kernel-argument segment (fit_table_kernarg).
 template <typename T>
-struct DevParams : TireFit<T> {
+struct DevCore {
     T inv_m, inv_Izz, inv_Jw;   // 1/m, 1/Izz (vehicle_model.py:376-378), 1/Jw (:379-382)
     T a, b, half_T, rw;         // geometry (:261-271,:378), wheel radius (:284)
     T Fz0F, Fz0R;               // static normal loads (:245-248)
@@ -62,18 +66,103 @@ struct DevParams : TireFit<T> {
     T invB[4];                  // 1/B: 1/(B s) = (1/s)(1/B) feeds atan's |x| > 1 branch for free
     T mu[4];                    // mu_max used by k = 2 controls (drive.py:142: [1,1,1,1])
 };
-
-// fp64 kernels: move the nineteen fit coefficients from the scalar to the vector registers once, at the top of the
-// kernel.  As wave-uniform kernel arguments they sit in SGPRs, and together with the other constants of the step
-// they overflow the scalar file: the compiler then spills SGPRs into VGPR lanes and reads them back one
-// `v_readlane_b32` at a time (105 per RK4 step before this, 9 % of the instruction stream).  (fp32: the packed
-// step pins its own pairs, PkParams::init.)
+template <typename T>
+struct DevParams : TireFit<T>, DevCore<T> {};
+__device__ __forceinline__ void pin_tire_fit(DevParams<float> &);
 __device__ __forceinline__ void pin_tire_fit(DevParams<double> &P)
 {
 #pragma unroll
-    for (int i = 0; i <= kTireFitDeg64; ++i) asm volatile("" : "+v"(P.W[i]));
+    for (int i = 0; i <= kTireFitDeg64; ++i) asm volatile("" : "+v"(P.W[i][0]));
 }
+
+// The fp64 fit table of the running kernel, W[i][wheel] at table[4 i + wheel]: offset 0 of the kernel-argument
+// segment (address space 4: constant memory -- a wave-uniform index is a scalar load).
+typedef const double __attribute__((address_space(4))) *vdyn_fit_table;
+__device__ __forceinline__ vdyn_fit_table fit_table_kernarg()
+{
+    return (vdyn_fit_table)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(18 - i).  The coefficients come from the
+// kernel-argument table two degrees (eight doubles = one s_load_dwordx16) at a time; the opaque pointer in front of
+// each group keeps the compiler from collecting all 76 of them at the top of the kernel, where they do not fit the
+// scalar file (105 v_readlane per step before round 2's fix), while each group's load still goes out ahead of the
+// previous group's eight fmas.
+// The lane kernels' copy of that table in LDS: 76 doubles, staged once per workgroup (stage_tire_fit), read back by
+// every lane at the same address -- a broadcast, no bank conflict.
+typedef double __attribute__((address_space(3))) *vdyn_lds_f64;
+__device__ __forceinline__ vdyn_lds_f64 fit_table_lds()
+{
+    __shared__ __align__(16) double s_fit[4 * (kTireFitDeg64 + 1)];
+    return (vdyn_lds_f64)s_fit;
+}
+template <typename T> struct DevParams;
+__device__ __forceinline__ void stage_tire_fit(const DevParams<float> &) {}        // fp32: PkParams pins its own pairs
+__device__ __forceinline__ void stage_tire_fit(const DevParams<double> &)
+{
+    const vdyn_lds_f64 t = fit_table_lds();
+    const vdyn_fit_table W = fit_table_kernarg();
+    for (int i = threadIdx.x; i < 4 * (kTireFitDeg64 + 1); i += blockDim.x) t[i] = W[i];
+    __syncthreads();
+}
+
+// fp64 handles whose four wheels share C (the reference's do, vehicle_model.py:44-45): column 0 of the table, moved from
+// the scalar to the vector registers once, at the top of the kernel.  As wave-uniform kernel arguments the nineteen
+// doubles sit in SGPRs, and together with the other constants of the step they overflow the scalar file: the compiler
+// then spills SGPRs into VGPR lanes and reads them back one `v_readlane_b32` at a time (105 per RK4 step before this,
+// 9 % of the instruction stream).  38 VGPRs is what the vector file has to spare: one set, not four.
 __device__ __forceinline__ void pin_tire_fit(DevParams<float> &) {}
+
+// W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(18 - i), the coefficients read from the
+// LDS table one degree (four doubles, two 16-byte reads) at a time.  Tried first: scalar loads straight from the
+// kernel-argument segment, the coefficient as the fma's scalar operand, two groups in flight -- no VGPR, no LDS, and
+// 0.64 ms instead of 0.42 on configs[1]: a scalar-cache hit is ~200 cycles, far more than the eight fp64 fmas it
+// was meant to hide behind, and deeper prefetch does not fit the scalar file.  LDS reads land in VGPRs, of which the
+// step has a hundred to spare once the pinned set of round 2 is gone, so the compiler runs them several degrees ahead.
+typedef double vdyn_d2v __attribute__((ext_vector_type(2)));
+#ifndef VDYN_FIT_KG
+#define VDYN_FIT_KG 2
+#define VDYN_FIT_AHEAD 3
+#endif
+__device__ __forceinline__ void fit_horner4_lds(const double cc[4], double g[4])
+{
+    // Groups of kG degrees (2 kG 16-byte reads, 8 kG VGPRs), kAhead groups read ahead of the one being evaluated: a
+    // group's reads may not start before all four chains have finished the group kAhead + 1 before it (the asm in
+    // front of them takes the chains as inputs).  Left alone, the scheduler issues the 38 reads of an evaluation at
+    // once, and the 152 registers they fill push the step into scratch.
+    typedef const vdyn_d2v __attribute__((address_space(3))) *lds_ptr;     // stays an LDS address (32 bits), never a flat one
+    const lds_ptr t0 = (lds_ptr)fit_table_lds();
+    constexpr int kG = VDYN_FIT_KG, kAhead = VDYN_FIT_AHEAD, kSlots = kAhead + 1;
+    constexpr int kRest = kTireFitDeg64 + 1 - 2;                       // degrees 2 .. 18
+    constexpr int kGroups = kRest / kG;                                // the last group takes the remainder too
+    constexpr int kLast = kRest - (kGroups - 1) * kG;
+    vdyn_d2v w[kSlots][2 * (kG + kG - 1)];
+    auto fetch = [&](int grp, lds_ptr t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2 * (grp == kGroups - 1 ? kLast : kG); ++q) w[grp % kSlots][q] = t[2 * (2 + grp * kG) + q];
+    };
+    lds_ptr t = t0;
+    asm volatile("" : "+v"(t) : "v"(cc[0]), "v"(cc[1]), "v"(cc[2]), "v"(cc[3]));
+    const vdyn_d2v a0 = t[0], a1 = t[1], b0 = t[2], b1 = t[3];
+#pragma unroll
+    for (int grp = 0; grp < kAhead && grp < kGroups; ++grp) fetch(grp, t);
+    g[0] = ::fma(a0.x, cc[0], b0.x); g[1] = ::fma(a0.y, cc[1], b0.y);
+    g[2] = ::fma(a1.x, cc[2], b1.x); g[3] = ::fma(a1.y, cc[3], b1.y);
+#pragma unroll
+    for (int grp = 0; grp < kGroups; ++grp) {
+        if (grp + kAhead < kGroups) {
+            lds_ptr tn = t0;
+            asm volatile("" : "+v"(tn) : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
+            fetch(grp + kAhead, tn);
+        }
+#pragma unroll
+        for (int d = 0; d < (grp == kGroups - 1 ? kLast : kG); ++d) {
+            const vdyn_d2v w0 = w[grp % kSlots][2 * d], w1 = w[grp % kSlots][2 * d + 1];
+            g[0] = ::fma(g[0], cc[0], w0.x); g[1] = ::fma(g[1], cc[1], w0.y);
+            g[2] = ::fma(g[2], cc[2], w1.x); g[3] = ::fma(g[3], cc[3], w1.y);
+        }
+    }
+}
 
 // ---- scalar math, by type and by path ------------------------------------------------
 template <typename T, bool SAFE> struct Math;
@@ -246,9 +335,12 @@ __device__ __forceinline__ void make_step_inv(const DevParams<T> &P, const T del
 // (fxt, fyt), chassis-frame force (fx, fy) and combined slip s.
 //   :274-281 rotation, :284-293 slips (quirk Q4: signed vx for s_x, |vx| for s_y),
 //   :296-299 combined slip, :303-348 Pacejka + split, :351-373 forces.
+// W (CS, trimmed step only): this wheel's fit coefficients in registers, W[i * ws], highest degree first -- the
+// wheel-parallel kernel (one wheel per lane) and the fleet kernel (constants per lane); kernels whose constants are
+// wave-uniform evaluate the four wheels together from the kernel-argument table instead (planar_deriv, KARG).
 template <typename T, bool STEERED, bool SAFE, bool CS>
-__device__ __forceinline__ void tire_force(T B, T invB, T C, const T *W, T rw, T vxc, T vyc, T w, T cd, T sd, T muFz,
-                                           T &fx, T &fy, T &fxt, T &fyt, T &s_out)
+__device__ __forceinline__ void tire_force(T B, T invB, T C, const T *W, int ws, T rw, T vxc, T vyc, T w, T cd, T sd,
+                                           T muFz, T &fx, T &fy, T &fxt, T &fyt, T &s_out)
 {
     using M = Math<T, SAFE>;
     T vx, vy;
@@ -268,9 +360,9 @@ __device__ __forceinline__ void tire_force(T B, T invB, T C, const T *W, T rw, T
         const T sxb = fma_t(rw, w, -vx) * rvxB;
         const T syb = -vy * abs_t(rvxB);
         const T cc = M::rsqrt(fma_t(sxb, sxb, fma_t(syb, syb, T(1))));
-        T g = fma_t(W[0], cc, W[1]);
+        T g = fma_t(W[0], cc, W[ws]);
 #pragma unroll
-        for (int i = 2; i <= kTireFitDeg64; ++i) g = fma_t(g, cc, W[i]);
+        for (int i = 2; i <= kTireFitDeg64; ++i) g = fma_t(g, cc, W[i * ws]);
         const T gf = g * (cc * muFz);
         fxt = sxb * gf;
         fyt = syb * gf;
@@ -324,7 +416,13 @@ struct Outputs18 {
 
 // State derivative, vehicle_model.py:220-425.  s[10] = U,V,wz,wFL,wFR,wRL,wRR,yaw,x,y;
 // (sy, cy) = sin, cos of s[7].  Returns k[10] and the body accelerations axc, ayc (:413-414).
-template <typename T, bool K2, bool DIAG, bool SAFE, bool CS>
+// FITSRC (fp64 trimmed CS step): 2 = the kernel staged the per-wheel fit table in LDS (stage_tire_fit) and the four
+// wheels are evaluated together (fit_horner4_lds); otherwise ONE set, column 0 of P's table -- pinned in VGPRs by the
+// kernel (pin_tire_fit) or part of the lane's own constants (fleet).
+__device__ __forceinline__ const double *fit_column0(const TireFit<double> &f) { return &f.W[0][0]; }
+__device__ __forceinline__ const float *fit_column0(const TireFit<float> &) { return nullptr; }
+
+template <typename T, bool K2, bool DIAG, bool SAFE, bool CS, int FITSRC = 1>
 __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepInv<T> &c, const T s[10],
                                              T sy, T cy, T k[10], T &axc, T &ayc, Outputs18<T> *out)
 {
@@ -335,14 +433,47 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
     const T vFy = V + P.a * wz, vRy = V - P.b * wz;
 
     T fx[4], fy[4], fxt[4], fyt[4], sl[4];
-    tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], tire_fit64(P), P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0],
-                              c.muFz[0], fx[0], fy[0], fxt[0], fyt[0], sl[0]);
-    tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], tire_fit64(P), P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1],
-                              c.muFz[1], fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-    tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], tire_fit64(P), P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
-                             c.muFz[2], fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-    tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], tire_fit64(P), P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
-                             c.muFz[3], fx[3], fy[3], fxt[3], fyt[3], sl[3]);
+    if constexpr (Math<T, SAFE>::kTrim && CS && FITSRC == 2 && sizeof(T) == 8) {
+        // the fitted chain of tire_force, the four wheels side by side: slips pre-multiplied by B, c = rsq(1 + x^2),
+        // W_C(c) of all four from the kernel-argument table, forces
+        using M = Math<T, SAFE>;
+        const T vxc[4] = {vLx, vRx, vLx, vRx}, vyc[4] = {vFy, vFy, vRy, vRy};
+        T sxb[4], syb[4], cc[4], g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool steered = i < 2 || !K2;
+            const T vx = steered ? vxc[i] * c.cd[i] + vyc[i] * c.sd[i] : vxc[i];
+            const T vy = steered ? vyc[i] * c.cd[i] - vxc[i] * c.sd[i] : vyc[i];
+            const T rvxB = M::rcp(vx) * P.B[i];
+            sxb[i] = fma_t(P.rw, s[3 + i], -vx) * rvxB;
+            syb[i] = -vy * abs_t(rvxB);
+            cc[i] = M::rsqrt(fma_t(sxb[i], sxb[i], fma_t(syb[i], syb[i], T(1))));
+        }
+        fit_horner4_lds(cc, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool steered = i < 2 || !K2;
+            const T gf = g[i] * (cc[i] * c.muFz[i]);
+            fxt[i] = sxb[i] * gf;
+            fyt[i] = syb[i] * gf;
+            fx[i] = steered ? fxt[i] * c.cd[i] - fyt[i] * c.sd[i] : fxt[i];
+            fy[i] = steered ? fxt[i] * c.sd[i] + fyt[i] * c.cd[i] : fyt[i];
+            if (DIAG) {   // the combined slip itself: |x| / B, exactly 0 at x = 0
+                const T x2 = fma_t(sxb[i], sxb[i], syb[i] * syb[i]);
+                sl[i] = x2 * M::rsqrt(x2 > tiny_t(T(0)) ? x2 : tiny_t(T(0))) * P.invB[i];
+            }
+        }
+    } else {
+        const T *W0 = fit_column0(P);
+        tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], W0, 4, P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0],
+                                      c.muFz[0], fx[0], fy[0], fxt[0], fyt[0], sl[0]);
+        tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], W0, 4, P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1],
+                                      c.muFz[1], fx[1], fy[1], fxt[1], fyt[1], sl[1]);
+        tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], W0, 4, P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
+                                     c.muFz[2], fx[2], fy[2], fxt[2], fyt[2], sl[2]);
+        tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], W0, 4, P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
+                                     c.muFz[3], fx[3], fy[3], fxt[3], fyt[3], sl[3]);
+    }
 
     // :376-385
     T Udot, Vdot;
@@ -391,7 +522,7 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
 // sn[10], (axn, ayn), the latter the 1-2-2-1 averages of axc, ayc (:442-443).
 // DIAG: also state_dot (:440) and the averaged outputs (:441).
 // Returns false for a lane that left the validated range of the FAST path.
-template <typename T, bool K2, bool DIAG, bool SAFE, bool CS, int PRE = 0>
+template <typename T, bool K2, bool DIAG, bool SAFE, bool CS, int PRE = 0, int FITSRC = 1>
 __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T ax, T ay, const T delta[4],
                                          const T tq[4], const T mu[4], T h, T sn[10], T &axn, T &ayn,
                                          T *state_dot, Outputs18<T> *outputs, T sd0 = T(0), T cd0 = T(1))
@@ -409,7 +540,7 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
     T sy0, cy0, sy, cy;
     M::sincos(s[7], &sy0, &cy0, ok);
 
-    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, s, M::kTrim ? T(0) : sy0, M::kTrim ? T(1) : cy0, k, a1, a2, &o);       // K1 (:429)
+    planar_deriv<T, K2, DIAG, SAFE, CS, FITSRC>(P, c, s, M::kTrim ? T(0) : sy0, M::kTrim ? T(1) : cy0, k, a1, a2, &o);       // K1 (:429)
     asx = a1; asy = a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = k[i]; st[i] = fma_t(hh, k[i], s[i]); }
@@ -422,7 +553,7 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
     T d2 = T(0), d3 = T(0), d4 = T(0);
     if (M::kTrim) { d2 = hh * k[7]; M::stage_rot(d2, &sy, &cy); }
     else M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
-    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K2 (:431)
+    planar_deriv<T, K2, DIAG, SAFE, CS, FITSRC>(P, c, st, sy, cy, k, a1, a2, &o);        // K2 (:431)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = fma_t(T(2), k[i], acc[i]); st[i] = fma_t(hh, k[i], s[i]); }
@@ -433,7 +564,7 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 
     if (M::kTrim) { d3 = hh * k[7]; M::stage_rot(d3, &sy, &cy); }
     else M::stage_sincos(sy0, cy0, st[7], hh * k[7], &sy, &cy, ok);
-    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K3 (:433)
+    planar_deriv<T, K2, DIAG, SAFE, CS, FITSRC>(P, c, st, sy, cy, k, a1, a2, &o);        // K3 (:433)
     asx += T(2) * a1; asy += T(2) * a2;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { acc[i] = fma_t(T(2), k[i], acc[i]); st[i] = fma_t(h, k[i], s[i]); }
@@ -444,7 +575,7 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 
     if (M::kTrim) { d4 = h * k[7]; M::stage_rot(d4, &sy, &cy); }
     else M::stage_sincos(sy0, cy0, st[7], h * k[7], &sy, &cy, ok);
-    planar_deriv<T, K2, DIAG, SAFE, CS>(P, c, st, sy, cy, k, a1, a2, &o);        // K4 (:435)
+    planar_deriv<T, K2, DIAG, SAFE, CS, FITSRC>(P, c, st, sy, cy, k, a1, a2, &o);        // K4 (:435)
     asx += a1; asy += a2;
     if (M::kTrim) {
         T m = abs_t(d2) > abs_t(d3) ? abs_t(d2) : abs_t(d3);
@@ -478,14 +609,14 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 __device__ __forceinline__ float atan_lib(float x) { return ::atanf(x); }
 __device__ __forceinline__ double atan_lib(double x) { return ::atan(x); }
 
-template <typename T, bool K2, bool DIAG, bool CS, int PRE = 0>
+template <typename T, bool K2, bool DIAG, bool CS, int PRE = 0, int FITSRC = 1>
 __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                             const T tq[4], const T mu[4], T h, T *state_dot,
                                             Outputs18<T> *outputs, T sd0 = T(0), T cd0 = T(1))
 {
     T sn[10], axn, ayn;
-    const bool ok = rk4_step<T, K2, DIAG, false, CS, PRE>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs,
-                                                          sd0, cd0);
+    const bool ok = rk4_step<T, K2, DIAG, false, CS, PRE, FITSRC>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot,
+                                                                outputs, sd0, cd0);
     if (Math<T, false>::kHasRangeLimit) {
         if (__builtin_expect(__any(!ok) != 0, 0)) {
             if (!ok) {

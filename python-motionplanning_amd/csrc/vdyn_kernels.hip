@@ -114,14 +114,20 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
 // issued a whole step earlier.  A/B on one box, two runs each: headline 0.1540 -> 0.1534 ms, per-rollout controls
 // (global loads) 0.1683 -> 0.1633 ms, configs[1] fp64 0.5235 -> 0.4927 ms; MPC and the closed loop unchanged.
 #define VDYN_FETCH_FENCE __builtin_amdgcn_sched_barrier(0);
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true>
+// PW (fp64, CS): the four wheels differ in C -- the per-wheel fit table goes to LDS and the step reads it from there
+// (fit_horner4_lds); otherwise the handle's one set is pinned in VGPRs (pin_tire_fit).
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true, bool PW = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
                T *__restrict__ terminal, T *__restrict__ traj, int traj_stride,
                T *__restrict__ state_dot_out, T *__restrict__ outputs_out)
 {
-    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
+    if (CS) {                           // only the fitted chain reads them
+        if (PW) stage_tire_fit(P);
+        else pin_tire_fit(P);
+    }
+    constexpr int FS = PW ? 2 : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *tab = reinterpret_cast<T *>(smem_raw);
 
@@ -174,16 +180,16 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             for (; tc + 3 < tc_n; tc += 4) {
                 fetch(c2, tc + 1);
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
                 fetch(c, tc + 2);
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
                 fetch(c2, tc + 3);
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
                 fetch(c, min(tc + 4, tc_n - 1));
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             }
         }
         for (; tc < tc_n; ++tc) {
@@ -201,7 +207,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 X.set(10, ax);
                 X.set(11, ay);
             } else {
-                eng.template advance_state<K == 2, CS, PRE>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
             }
             c = cn;
 
@@ -302,7 +308,32 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
 // through LDS once per workgroup and each lane copies its class's row into registers.  (With one
 // class -- every BASELINE configuration -- the constants are wave-uniform and the kernel above
 // keeps them in SGPRs instead, which is cheaper than any LDS read.)
-template <typename T> constexpr int dev_params_len() { return (int)(sizeof(DevParams<T>) / sizeof(T)); }
+// One class of the fleet table, as plain T words.  fp32: the whole DevParams (its per-wheel fits are 36 floats).  fp64:
+// ONE set of fit coefficients + the rest -- 76 doubles of per-wheel fits per class would neither fit LDS for 256
+// classes nor a lane's registers, so an fp64 class takes the fitted chain only when its four wheels share C
+// (build_fleet_table) and the lane carries that set as column 0 of its DevParams.
+template <typename T> struct FleetRow;
+template <> struct FleetRow<float> {
+    DevParams<float> p;
+    __device__ __forceinline__ void unpack(DevParams<float> &P) const { P = p; }
+    void pack(const DevParams<float> &d) { p = d; }
+};
+template <> struct FleetRow<double> {
+    double W[kTireFitDeg64 + 1];
+    DevCore<double> core;
+    __device__ __forceinline__ void unpack(DevParams<double> &P) const
+    {
+        static_cast<DevCore<double> &>(P) = core;
+#pragma unroll
+        for (int i = 0; i <= kTireFitDeg64; ++i) P.W[i][0] = W[i];
+    }
+    void pack(const DevParams<double> &d)
+    {
+        core = static_cast<const DevCore<double> &>(d);
+        for (int i = 0; i <= kTireFitDeg64; ++i) W[i] = d.W[i][0];
+    }
+};
+template <typename T> constexpr int dev_params_len() { return (int)(sizeof(FleetRow<T>) / sizeof(T)); }
 
 template <typename T, int K, int LAYOUT, bool CS>
 __global__ void __launch_bounds__(kBlock)
@@ -323,9 +354,11 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
     DevParams<T> P;
     {
         const int vid = min(max(vehicle_id[r], 0), V - 1);
-        T *dst = reinterpret_cast<T *>(&P);
+        FleetRow<T> row;
+        T *dst = reinterpret_cast<T *>(&row);
 #pragma unroll
         for (int i = 0; i < NP; ++i) dst[i] = lds_fleet[vid * NP + i];
+        row.unpack(P);
     }
     T s[10], ax, ay;
 #pragma unroll
@@ -385,7 +418,6 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
                     const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
                     T *__restrict__ terminal, T *__restrict__ traj, int traj_stride)
 {
-    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *tab = reinterpret_cast<T *>(smem_raw);
 
@@ -1333,9 +1365,9 @@ fastmath_eval_kernel(int fn, int64_t n, const T *__restrict__ x, T c, TireFit<T>
             if (fn == 5) {
                 // the trimmed fp64 step's tire chain (tire_force in vdyn_device.hpp) with the fit of C = c
                 const T cc = Math<T, false>::rsqrt(fma_t(v, v, T(1)));
-                T g = fma_t(fit.W[0], cc, fit.W[1]);
+                T g = fma_t(fit.W[0][0], cc, fit.W[1][0]);
 #pragma unroll
-                for (int j = 2; j <= kTireFitDeg64; ++j) g = fma_t(g, cc, fit.W[j]);
+                for (int j = 2; j <= kTireFitDeg64; ++j) g = fma_t(g, cc, fit.W[j][0]);
                 b = g * cc;
                 a = g * (cc * v);
                 two = true;
@@ -1441,7 +1473,7 @@ struct TireFitC {
 struct TireFitHost {
     double C[4];
     float W[kTireFitDeg + 1][4];
-    double W64[kTireFitDeg64 + 1];
+    double W64[kTireFitDeg64 + 1][4];
     bool ok, ok64, filled;
 };
 
@@ -1466,20 +1498,16 @@ static const TireFitC &tire_fit_c(double C)
 
 static const TireFitHost &tire_fit(const VdynParams &p)
 {
-    static thread_local TireFitHost cache = {{0, 0, 0, 0}, {{0}}, {0}, false, false, false};
+    static thread_local TireFitHost cache = {{0, 0, 0, 0}, {{0}}, {{0}}, false, false, false};
     if (cache.filled && std::memcmp(cache.C, p.C, sizeof(cache.C)) == 0) return cache;
-    cache.ok = true;
+    cache.ok = cache.ok64 = true;
     for (int w = 0; w < 4; ++w) {
         const TireFitC e = tire_fit_c(p.C[w]);        // by value: a later lookup may recycle the slot
         cache.ok = cache.ok && e.ok;
+        cache.ok64 = cache.ok64 && e.ok64;
         for (int i = 0; i <= kTireFitDeg; ++i) cache.W[i][w] = e.W[i];
-        if (w == 0) {
-            std::memcpy(cache.W64, e.W64, sizeof(cache.W64));
-            cache.ok64 = e.ok64;
-        }
+        for (int i = 0; i <= kTireFitDeg64; ++i) cache.W64[i][w] = e.W64[i];
     }
-    // fp64: one set of coefficients, so the four wheels must share C
-    cache.ok64 = cache.ok64 && p.C[0] == p.C[1] && p.C[0] == p.C[2] && p.C[0] == p.C[3];
     std::memcpy(cache.C, p.C, sizeof(cache.C));
     cache.filled = true;
     return cache;
@@ -1525,15 +1553,20 @@ static bool stiffness_nonnegative(const VdynParams &p)
 }
 
 // The CS flag of the kernels: the FAST step runs the handle's fitted tire chain.  Needs B >= 0 on every wheel and
-// fits that passed their check (any C for which they do: 0 up to about 2.9; fp64 also the same C on all wheels).
+// fits that passed their check (any C for which they do: 0 up to about 2.9), per wheel in both precisions.
+static bool same_shape_factor(const VdynParams &p) { return p.C[0] == p.C[1] && p.C[0] == p.C[2] && p.C[0] == p.C[3]; }
+
+// per_wheel: the kernel takes a fit per wheel (fp32: all of them; fp64: the rollout kernel through LDS, the
+// wheel-parallel one in registers); the other fp64 kernels carry ONE set and need the four wheels to share C.
 template <typename T>
-static bool lane_cs(const VdynParams &p)
+static bool lane_cs(const VdynParams &p, bool per_wheel = false)
 {
     if (!stiffness_nonnegative(p)) return false;
-    return std::is_same<T, float>::value ? tire_fit(p).ok : tire_fit(p).ok64;
+    if (std::is_same<T, float>::value) return tire_fit(p).ok;
+    return tire_fit(p).ok64 && (per_wheel || same_shape_factor(p));
 }
 
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS>
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool PW = false>
 static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
 {
     const DevParams<T> P = make_dev_params<T>(p, a.mu4);
@@ -1546,11 +1579,11 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
         lds = (size_t)chunk * per_step;
     }
     if (a.traj != nullptr || DIAG)
-        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true, PW>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
                            a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
                            a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
     else
-        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false, PW>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
                            a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
                            a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
     return hipGetLastError();
@@ -1586,8 +1619,12 @@ void build_fleet_table(const VdynParams *classes, int V, const double *mu4, T *o
     *all_small = true;
     for (int v = 0; v < V; ++v) {
         const DevParams<T> d = make_dev_params<T>(classes[v], mu4);
-        std::memcpy(out + (size_t)v * dev_params_len<T>(), &d, sizeof(d));
-        *all_small = *all_small && lane_cs<T>(classes[v]);
+        FleetRow<T> row;
+        row.pack(d);
+        std::memcpy(out + (size_t)v * dev_params_len<T>(), &row, sizeof(row));
+        const double *C = classes[v].C;
+        const bool one_set = sizeof(T) == 4 || (C[0] == C[1] && C[0] == C[2] && C[0] == C[3]);   // FleetRow<double>
+        *all_small = *all_small && lane_cs<T>(classes[v]) && one_set;
     }
 }
 template <typename T> int fleet_table_len(int V) { return V * dev_params_len<T>(); }
@@ -1643,7 +1680,8 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     // one step of the table must fit the LDS budget (k = 2 tables are staged 4 wide, see rollout_table_pre)
     if (layout == VDYN_CTRL_SHARED && (size_t)a.P * (a.k == 2 ? 4 : a.k) * sizeof(T) > (size_t)kLdsBudget) layout = 2;
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
-    const bool cs = lane_cs<T>(p), cs_quad = cs;
+    const bool cs_quad = lane_cs<T>(p, true);                   // a lane of the wheel-parallel kernel holds its own wheel's fit
+    const bool cs = cs_quad, pw = sizeof(T) == 8 && cs && !same_shape_factor(p);
     if (a.lanes_per_rollout == 4 && !diag) {
 #define VDYN_DISPATCH_Q(KK, LL)                                                        \
     if (a.k == KK && layout == LL)                                                     \
@@ -1659,10 +1697,13 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     }
     // the diagnostic (single-step drop-in) variants are launch-latency bound: general form only
 #define VDYN_DISPATCH(KK, LL)                                                          \
-    if (a.k == KK && layout == LL)                                                     \
-        return diag ? launch_rollout_impl<T, KK, LL, true, false>(p, a, st)            \
-               : cs ? launch_rollout_impl<T, KK, LL, false, true>(p, a, st)            \
-                    : launch_rollout_impl<T, KK, LL, false, false>(p, a, st);
+    if (a.k == KK && layout == LL) {                                                   \
+        if (diag) return launch_rollout_impl<T, KK, LL, true, false>(p, a, st);        \
+        if constexpr (sizeof(T) == 8)                                                  \
+            if (pw) return launch_rollout_impl<T, KK, LL, false, true, true>(p, a, st); \
+        return cs ? launch_rollout_impl<T, KK, LL, false, true>(p, a, st)              \
+                  : launch_rollout_impl<T, KK, LL, false, false>(p, a, st);            \
+    }
     VDYN_DISPATCH(2, 0)
     VDYN_DISPATCH(2, 1)
     VDYN_DISPATCH(2, 2)

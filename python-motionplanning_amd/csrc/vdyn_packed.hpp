@@ -540,11 +540,12 @@ struct StepEngine {
         __device__ __forceinline__ T get(int i) const { return i < 10 ? s[i] : (i == 10 ? ax : ay); }
         __device__ __forceinline__ void set(int i, T v) { if (i < 10) s[i] = v; else if (i == 10) ax = v; else ay = v; }
     };
-    template <bool K2, bool CS, int PRE = 0>
+    // FITSRC = 2: the kernel staged the per-wheel fp64 fit table in LDS (planar_deriv)
+    template <bool K2, bool CS, int PRE = 0, int FITSRC = 1>
     __device__ __forceinline__ void advance_state(const DevParams<T> &P, State &X, const T delta[4], const T tq[4],
                                                   const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
     {
-        rk4_advance<T, K2, false, CS, PRE>(P, X.s, X.ax, X.ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
+        rk4_advance<T, K2, false, CS, PRE, FITSRC>(P, X.s, X.ax, X.ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
     }
     template <bool UNIFORM = true, bool FIT = false>
     __device__ __forceinline__ void init(const DevParams<T> &) {}
@@ -553,11 +554,13 @@ struct StepEngine {
         bool ok = true;
         Math<T, false>::sincos_steer(d, &sd, &cd, ok);
     }
+    // constants PER LANE (heterogeneous fleet): P lives in the lane's registers and carries one set of fp64 fit
+    // coefficients (column 0)
     template <bool K2, bool CS, int PRE = 0>
     __device__ __forceinline__ void advance(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                             const T tq[4], const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
     {
-        rk4_advance<T, K2, false, CS, PRE>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
+        rk4_advance<T, K2, false, CS, PRE, 1>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
     }
     // the same step with state_dot [10] and the averaged outputs [18] (vehicle_model.py:440-441)
     template <bool K2, bool CS>
@@ -610,7 +613,7 @@ struct StepEngine<float> {
             }
         }
     };
-    template <bool K2, bool CS, int PRE = 0>
+    template <bool K2, bool CS, int PRE = 0, int FITSRC = 1>      // FITSRC: fp64 only (the packed step carries four fits)
     __device__ __forceinline__ void advance_state(const DevParams<float> &P, State &X, const float delta[4],
                                                   const float tq[4], const float mu[4], float h, float sd0 = 0.0f,
                                                   float cd0 = 1.0f) const

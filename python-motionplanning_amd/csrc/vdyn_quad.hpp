@@ -99,8 +99,9 @@ struct QuadState {
 };
 
 // One derivative evaluation (vehicle_model.py:220-425) spread over a quad.
+// fit: this lane's wheel's fit coefficients (fp64 CS; QuadEngine keeps them in registers), highest degree first.
 template <typename T, bool SAFE, bool CS>
-__device__ __forceinline__ void planar_deriv_quad(const DevParams<T> &P, const WheelLane<T> &L, T cd, T sd,
+__device__ __forceinline__ void planar_deriv_quad(const DevParams<T> &P, const WheelLane<T> &L, const T *fit, T cd, T sd,
                                                   T muFz, T tq, const QuadState<T> &s, T sy, T cy,
                                                   QuadState<T> &k, T &axc, T &ayc)
 {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void planar_deriv_quad(const DevParams<T> &P, const W
     const T vxc = fma_t(L.side, hTw, s.U);          // U -+ T wz / 2
     const T vyc = fma_t(L.lever, s.wz, s.V);        // V + a wz | V - b wz
     T fx, fy, fxt, fyt, slip;
-    tire_force<T, true, SAFE, CS>(L.B, L.invB, L.C, tire_fit64(P), P.rw, vxc, vyc, s.w, cd, sd,
+    tire_force<T, true, SAFE, CS>(L.B, L.invB, L.C, fit, 1, P.rw, vxc, vyc, s.w, cd, sd,
                                   muFz, fx, fy, fxt, fyt, slip);
     const T Sfx = quad_sum(fx);
     const T Sfy = quad_sum(fy);
@@ -128,9 +129,9 @@ __device__ __forceinline__ void planar_deriv_quad(const DevParams<T> &P, const W
 // RK4 (vehicle_model.py:427-445) for one lane of a quad.  Returns false when the lane left the
 // validated range of the FAST path.
 template <typename T, bool SAFE, bool CS>
-__device__ __forceinline__ bool rk4_step_quad(const DevParams<T> &P, const WheelLane<T> &L, const QuadState<T> &s,
-                                              T ax, T ay, T delta, T tq, T mu, T h, QuadState<T> &sn, T &axn,
-                                              T &ayn)
+__device__ __forceinline__ bool rk4_step_quad(const DevParams<T> &P, const WheelLane<T> &L, const T *fw,
+                                              const QuadState<T> &s, T ax, T ay, T delta, T tq, T mu, T h,
+                                              QuadState<T> &sn, T &axn, T &ayn)
 {
     using M = Math<T, SAFE>;
     bool ok = true;
@@ -144,22 +145,22 @@ __device__ __forceinline__ bool rk4_step_quad(const DevParams<T> &P, const Wheel
     QuadState<T> k, acc, st;
 
 #define VDYN_Q_EACH(OP) OP(U) OP(V) OP(wz) OP(w) OP(yaw) OP(x) OP(y)
-    planar_deriv_quad<T, SAFE, CS>(P, L, cd, sd, muFz, tq, s, sy0, cy0, k, a1, a2);        // K1
+    planar_deriv_quad<T, SAFE, CS>(P, L, fw, cd, sd, muFz, tq, s, sy0, cy0, k, a1, a2);        // K1
     asx = a1; asy = a2;
 #define VDYN_Q_1(f) acc.f = k.f; st.f = fma_t(hh, k.f, s.f);
     VDYN_Q_EACH(VDYN_Q_1)
     M::stage_sincos(sy0, cy0, st.yaw, hh * k.yaw, &sy, &cy, ok);
-    planar_deriv_quad<T, SAFE, CS>(P, L, cd, sd, muFz, tq, st, sy, cy, k, a1, a2);         // K2
+    planar_deriv_quad<T, SAFE, CS>(P, L, fw, cd, sd, muFz, tq, st, sy, cy, k, a1, a2);         // K2
     asx += T(2) * a1; asy += T(2) * a2;
 #define VDYN_Q_2(f) acc.f = fma_t(T(2), k.f, acc.f); st.f = fma_t(hh, k.f, s.f);
     VDYN_Q_EACH(VDYN_Q_2)
     M::stage_sincos(sy0, cy0, st.yaw, hh * k.yaw, &sy, &cy, ok);
-    planar_deriv_quad<T, SAFE, CS>(P, L, cd, sd, muFz, tq, st, sy, cy, k, a1, a2);         // K3
+    planar_deriv_quad<T, SAFE, CS>(P, L, fw, cd, sd, muFz, tq, st, sy, cy, k, a1, a2);         // K3
     asx += T(2) * a1; asy += T(2) * a2;
 #define VDYN_Q_3(f) acc.f = fma_t(T(2), k.f, acc.f); st.f = fma_t(h, k.f, s.f);
     VDYN_Q_EACH(VDYN_Q_3)
     M::stage_sincos(sy0, cy0, st.yaw, h * k.yaw, &sy, &cy, ok);
-    planar_deriv_quad<T, SAFE, CS>(P, L, cd, sd, muFz, tq, st, sy, cy, k, a1, a2);         // K4
+    planar_deriv_quad<T, SAFE, CS>(P, L, fw, cd, sd, muFz, tq, st, sy, cy, k, a1, a2);         // K4
     asx += a1; asy += a2;
     const T h6 = h * T(1.0 / 6.0), sixth = T(1.0 / 6.0);
 #define VDYN_Q_4(f) sn.f = fma_t(h6, acc.f + k.f, s.f);
@@ -176,16 +177,16 @@ __device__ __forceinline__ bool rk4_step_quad(const DevParams<T> &P, const Wheel
 
 // FAST step, then SAFE for whole quads in which any lane left the validated range.
 template <typename T, bool CS>
-__device__ __forceinline__ void rk4_advance_quad(const DevParams<T> &P, const WheelLane<T> &L, QuadState<T> &s,
-                                                 T &ax, T &ay, T delta, T tq, T mu, T h)
+__device__ __forceinline__ void rk4_advance_quad(const DevParams<T> &P, const WheelLane<T> &L, const T *fw,
+                                                 QuadState<T> &s, T &ax, T &ay, T delta, T tq, T mu, T h)
 {
     QuadState<T> sn;
     T axn, ayn;
-    const bool ok = rk4_step_quad<T, false, CS>(P, L, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
+    const bool ok = rk4_step_quad<T, false, CS>(P, L, fw, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
     if (Math<T, false>::kHasRangeLimit) {
         const bool okq = quad_all(ok);
         if (__builtin_expect(__any(!okq) != 0, 0)) {
-            if (!okq) rk4_step_quad<T, true, CS>(P, L, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
+            if (!okq) rk4_step_quad<T, true, CS>(P, L, fw, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
         }
     }
     s = sn;

@@ -29,13 +29,20 @@ __device__ __forceinline__ f2 pk_rot90(f2 a, f2 b)        // (-a.y b.x, a.x b.x)
 }
 
 template <typename T>
-struct QuadEngine {
-    __device__ __forceinline__ void init(const DevParams<T> &, const WheelLane<T> &, int) {}
+struct QuadEngine {           // fp64: the scalar step; this lane's wheel's nineteen fit coefficients in registers
+    T fw[kTireFitDeg64 + 1];
+    __device__ __forceinline__ void init(const DevParams<T> &, const WheelLane<T> &, int q)
+    {
+        // column q of the kernel-argument table (fit_table_kernarg): a per-lane index, so ordinary (vector) loads
+        vdyn_fit_table W = fit_table_kernarg();
+#pragma unroll
+        for (int i = 0; i <= kTireFitDeg64; ++i) fw[i] = (T)W[4 * i + q];
+    }
     template <bool CS>
     __device__ __forceinline__ void advance(const DevParams<T> &P, const WheelLane<T> &L, QuadState<T> &s, T &ax,
                                             T &ay, T delta, T tq, T mu, T h) const
     {
-        rk4_advance_quad<T, CS>(P, L, s, ax, ay, delta, tq, mu, h);
+        rk4_advance_quad<T, CS>(P, L, fw, s, ax, ay, delta, tq, mu, h);
     }
 };
 
@@ -214,7 +221,7 @@ struct QuadEngine<float> {
                                             float mu, float h) const
     {
         if (!CS) {
-            rk4_advance_quad<float, CS>(P, L, s, ax, ay, delta, tq, mu, h);
+            rk4_advance_quad<float, CS>(P, L, nullptr, s, ax, ay, delta, tq, mu, h);
             return;
         }
         Lane3 S, Sn;
@@ -230,7 +237,7 @@ struct QuadEngine<float> {
         float axn = axy_n.x, ayn = axy_n.y;
         const bool okq = quad_all(ok);                                    // the whole quad redoes the step together
         if (__builtin_expect(__any(!okq) != 0, 0)) {
-            if (!okq) rk4_step_quad<float, true, CS>(P, L, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
+            if (!okq) rk4_step_quad<float, true, CS>(P, L, nullptr, s, ax, ay, delta, tq, mu, h, sn, axn, ayn);
         }
         s = sn;
         ax = axn;
