@@ -104,8 +104,18 @@ const char *vdyn_last_error(const VdynHandle *h);
  *   4            wheel-parallel, four lanes per rollout: 2-3x shorter serial chain, meant for
  *                small N where the chip is mostly empty; agrees with 1 to rounding
  *                (different summation order of the four tire forces), not bit for bit;
- *   0            automatic: 4 when N <= 16384 (fp32) / 32768 (fp64), else 1.               */
-enum { VDYN_OPT_LANES_PER_ROLLOUT = 1 };
+ *   0            automatic: 4 when N <= 16384 (fp32) / 32768 (fp64), else 1.
+ * VDYN_OPT_STATE_ROWS: rows of the state arrays of vdyn_rollout_f32_* (state0 and terminal).
+ *   12 (default) U V wz wFL wFR wRL wRR yaw x y ax_prev ay_prev;
+ *   22           the same + rows 12..21 = the compensation terms of rows 0..9: the fp32 state accumulation
+ *                s <- s + h/6 (K1 + 2 K2 + 2 K3 + K4) (vehicle_model.py:438) is then a compensated (Kahan) sum --
+ *                what rounding loses at one step is carried in row 12 + i and given back at the next.  BASELINE's
+ *                second metric, the fp32 max-abs state error, is dominated by exactly that rounding at |x| ~ 100 m
+ *                (4e-4 after 200 steps, 9e-4 after 1000); compensated it stays near 3e-5 for +3 % time.  Start with
+ *                zeros in rows 12..21; a terminal state fed back as state0 continues the very same sum, so
+ *                rollout(a) then rollout(b) equals rollout(a + b) bit for bit, as with 12 rows.  fp32,
+ *                lane-per-rollout, fitted tire chain only (VDYN_ERR_ARG otherwise); trajectories keep 12 rows.   */
+enum { VDYN_OPT_LANES_PER_ROLLOUT = 1, VDYN_OPT_STATE_ROWS = 2 };
 int vdyn_set_option(VdynHandle *h, int option, int value);
 /* hipStreamSynchronize(stream) for callers that have no HIP binding of their own. */
 int vdyn_stream_synchronize(VdynHandle *h, void *stream);

@@ -15,6 +15,7 @@ VDYN_ABI_VERSION = 2
 VDYN_OK, VDYN_ERR_ARG, VDYN_ERR_HIP, VDYN_ERR_NODEV, VDYN_ERR_OOM = 0, -1, -2, -3, -4
 VDYN_CTRL_PER_ROLLOUT, VDYN_CTRL_SHARED = 0, 1
 VDYN_OPT_LANES_PER_ROLLOUT = 1
+VDYN_OPT_STATE_ROWS = 2
 
 
 class VdynError(RuntimeError):

@@ -20,6 +20,7 @@ struct VdynHandle {
     void *h_pinned = nullptr;
     size_t h_bytes = 0;
     int lanes_per_rollout = 1;      // VDYN_OPT_LANES_PER_ROLLOUT
+    int state_rows = 12;            // VDYN_OPT_STATE_ROWS
     void *d_fleet = nullptr;        // device copy of the per-class constants of the last fleet call
     size_t d_fleet_bytes = 0;
     void *d_aux = nullptr;          // controllers' auxiliary waypoint tables (segment lengths, bounding circles)
@@ -197,6 +198,10 @@ int vdyn_set_option(VdynHandle *h, int option, int value)
         h->lanes_per_rollout = value;
         return VDYN_OK;
     }
+    if (option == VDYN_OPT_STATE_ROWS && (value == 12 || value == 22)) {
+        h->state_rows = value;
+        return VDYN_OK;
+    }
     return h->fail(VDYN_ERR_ARG, "vdyn_set_option: unknown option or value");
 }
 
@@ -333,12 +338,21 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     if (a.traj && a.traj_stride <= 0) return h->fail(VDYN_ERR_ARG, w + ": traj needs traj_stride > 0");
     VDYN_HIP(h, hipSetDevice(h->device));
     vdyn::RolloutArgs<T> b = a;
+    b.state_rows = h->state_rows;
+    if (b.state_rows != 12) {
+        if (sizeof(T) != 4) return h->fail(VDYN_ERR_ARG, w + ": VDYN_OPT_STATE_ROWS = 22 is an fp32 option");
+        if (a.state_dot || a.outputs) return h->fail(VDYN_ERR_ARG, w + ": no diagnostics with VDYN_OPT_STATE_ROWS = 22");
+    }
     // 0 = automatic: wheel-parallel while it is measurably faster (tools/sweep_lanes.py at the
     // sustained clock, against the lane kernel, round 2's builds: fp32 1.42x up to 16384 rollouts, 0.84x at
     // 24576; fp64 1.92x up to 16384, 1.17x at 32768, 0.80x at 40960)
     const int64_t auto_max = sizeof(T) == 4 ? 16384 : 32768;
     b.lanes_per_rollout = h->lanes_per_rollout == 0 ? (a.n <= auto_max ? 4 : 1) : h->lanes_per_rollout;
-    VDYN_HIP(h, vdyn::launch_rollout<T>(h->p, b, (hipStream_t)stream));
+    if (b.state_rows != 12) b.lanes_per_rollout = 1;         // the compensated sum lives in the lane kernel
+    const hipError_t launched = vdyn::launch_rollout<T>(h->p, b, (hipStream_t)stream);
+    if (launched == hipErrorInvalidValue && b.state_rows != 12)
+        return h->fail(VDYN_ERR_ARG, w + ": VDYN_OPT_STATE_ROWS = 22 needs the fitted tire chain (B >= 0, validated fits)");
+    VDYN_HIP(h, launched);
     return VDYN_OK;
 }
 
@@ -615,9 +629,10 @@ int rollout_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
                                   ? (size_t)a.H * a.k * e
                                   : sizeof(T) * (size_t)a.P * a.H * a.k;
     Stage s(h);
-    const size_t i0 = s.in(a.state0, 12 * e), i1 = s.in(a.ctrl, ctrl_bytes),
+    const size_t rows = (size_t)h->state_rows;
+    const size_t i0 = s.in(a.state0, rows * e), i1 = s.in(a.ctrl, ctrl_bytes),
                  i2 = s.in(a.path_id, a.layout == VDYN_CTRL_SHARED ? sizeof(int32_t) * (size_t)a.n : 0);
-    const size_t o0 = s.out(a.terminal, 12 * e),
+    const size_t o0 = s.out(a.terminal, rows * e),
                  o1 = s.out(a.traj, a.traj ? (size_t)(a.H / a.traj_stride) * 12 * e : 0),
                  o2 = s.out(a.state_dot, 10 * e), o3 = s.out(a.outputs, 18 * e);
     int rc = s.upload();

@@ -28,6 +28,7 @@ struct RolloutArgs {
     T *state_dot = nullptr;      // nullable, last step's RK4-averaged derivative [10][n]
     T *outputs = nullptr;        // nullable, last step's RK4-averaged outputs   [18][n]
     int lanes_per_rollout = 1;   // 1: lane per rollout; 4: wheel-parallel (vdyn_quad.hpp)
+    int state_rows = 12;         // 22: state0 / terminal carry the compensation terms (VDYN_OPT_STATE_ROWS; fp32 only)
     const T *fleet_tab = nullptr;      // fleet rollouts: device table [V][len] of per-class constants
     const int *vehicle_id = nullptr;   // fleet rollouts: device [n], class of every rollout
     int V = 0;

@@ -116,7 +116,9 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
 #define VDYN_FETCH_FENCE __builtin_amdgcn_sched_barrier(0);
 // PW (fp64, CS): the four wheels differ in C -- the per-wheel fit table goes to LDS and the step reads it from there
 // (fit_horner4_lds); otherwise the handle's one set is pinned in VGPRs (pin_tire_fit).
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true, bool PW = false>
+// COMP (fp32, CS): state0 / terminal are [22][n], rows 12..21 the compensation terms of the state sum
+// (VDYN_OPT_STATE_ROWS, StepEngine<float>::advance_state); trajectories keep 12 rows.
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true, bool PW = false, bool COMP = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
@@ -136,8 +138,9 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     const int64_t r = active ? gid : n - 1;  // idle lanes shadow the last rollout, stores masked
 
     typename StepEngine<T>::State X;
+    constexpr int kRows = COMP ? 22 : 12;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) X.set(i, state0[(int64_t)i * n + r]);
+    for (int i = 0; i < kRows; ++i) X.set(i, state0[(int64_t)i * n + r]);
 
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);  // ids outside [0, P) are clamped, never read out of bounds
@@ -180,16 +183,16 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             for (; tc + 3 < tc_n; tc += 4) {
                 fetch(c2, tc + 1);
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
                 fetch(c, tc + 2);
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
                 fetch(c2, tc + 3);
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
                 fetch(c, min(tc + 4, tc_n - 1));
                 VDYN_FETCH_FENCE
-                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             }
         }
         for (; tc < tc_n; ++tc) {
@@ -207,7 +210,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 X.set(10, ax);
                 X.set(11, ay);
             } else {
-                eng.template advance_state<K == 2, CS, PRE, FS>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
             }
             c = cn;
 
@@ -221,7 +224,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
 
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) terminal[(int64_t)i * n + r] = X.get(i);
+        for (int i = 0; i < kRows; ++i) terminal[(int64_t)i * n + r] = X.get(i);
         if (DIAG) {
             if (state_dot_out != nullptr && H > 0) {
 #pragma unroll
@@ -1566,7 +1569,7 @@ static bool lane_cs(const VdynParams &p, bool per_wheel = false)
     return tire_fit(p).ok64 && (per_wheel || same_shape_factor(p));
 }
 
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool PW = false>
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool PW = false, bool COMP = false>
 static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
 {
     const DevParams<T> P = make_dev_params<T>(p, a.mu4);
@@ -1579,11 +1582,11 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
         lds = (size_t)chunk * per_step;
     }
     if (a.traj != nullptr || DIAG)
-        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true, PW>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true, PW, COMP>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
                            a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
                            a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
     else
-        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false, PW>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
+        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false, PW, COMP>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
                            a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
                            a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
     return hipGetLastError();
@@ -1682,6 +1685,23 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
     const bool cs_quad = lane_cs<T>(p, true);                   // a lane of the wheel-parallel kernel holds its own wheel's fit
     const bool cs = cs_quad, pw = sizeof(T) == 8 && cs && !same_shape_factor(p);
+    if (a.state_rows == 22) {
+        // compensated state sum: fp32, lane per rollout, fitted chain (anything else: invalid value -> VDYN_ERR_ARG)
+        if constexpr (sizeof(T) == 4) {
+            if (cs && !diag) {
+#define VDYN_DISPATCH_C(KK, LL) \
+    if (a.k == KK && layout == LL) return launch_rollout_impl<T, KK, LL, false, true, false, true>(p, a, st);
+                VDYN_DISPATCH_C(2, 0)
+                VDYN_DISPATCH_C(2, 1)
+                VDYN_DISPATCH_C(2, 2)
+                VDYN_DISPATCH_C(12, 0)
+                VDYN_DISPATCH_C(12, 1)
+                VDYN_DISPATCH_C(12, 2)
+#undef VDYN_DISPATCH_C
+            }
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.lanes_per_rollout == 4 && !diag) {
 #define VDYN_DISPATCH_Q(KK, LL)                                                        \
     if (a.k == KK && layout == LL)                                                     \

@@ -541,7 +541,7 @@ struct StepEngine {
         __device__ __forceinline__ void set(int i, T v) { if (i < 10) s[i] = v; else if (i == 10) ax = v; else ay = v; }
     };
     // FITSRC = 2: the kernel staged the per-wheel fp64 fit table in LDS (planar_deriv)
-    template <bool K2, bool CS, int PRE = 0, int FITSRC = 1>
+    template <bool K2, bool CS, int PRE = 0, int FITSRC = 1, bool COMP = false>       // COMP: fp32 only
     __device__ __forceinline__ void advance_state(const DevParams<T> &P, State &X, const T delta[4], const T tq[4],
                                                   const T mu[4], T h, T sd0 = T(0), T cd0 = T(1)) const
     {
@@ -595,13 +595,17 @@ struct StepEngine<float> {
     // unpacks nor re-packs anything.
     struct State {
         f2 uv, wy, wf, wr, xy, axy;
-        // rows of the [12][N] layout: U V wz wFL wFR wRL wRR yaw x y ax ay
+        f2 cuv, cwy, cwf, cwr, cxy;          // compensation terms of the five pairs (COMP kernels only; dead elsewhere)
+        // rows of the [12][N] layout: U V wz wFL wFR wRL wRR yaw x y ax ay; rows 12..21 of the [22][N] layout
+        // (VDYN_OPT_STATE_ROWS): the compensation terms of rows 0..9
         __device__ __forceinline__ float get(int i) const
         {
             switch (i) {
             case 0: return uv.x; case 1: return uv.y; case 2: return wy.x; case 3: return wf.x; case 4: return wf.y;
             case 5: return wr.x; case 6: return wr.y; case 7: return wy.y; case 8: return xy.x; case 9: return xy.y;
-            case 10: return axy.x; default: return axy.y;
+            case 10: return axy.x; case 11: return axy.y;
+            case 12: return cuv.x; case 13: return cuv.y; case 14: return cwy.x; case 15: return cwf.x; case 16: return cwf.y;
+            case 17: return cwr.x; case 18: return cwr.y; case 19: return cwy.y; case 20: return cxy.x; default: return cxy.y;
             }
         }
         __device__ __forceinline__ void set(int i, float v)
@@ -609,11 +613,18 @@ struct StepEngine<float> {
             switch (i) {
             case 0: uv.x = v; break; case 1: uv.y = v; break; case 2: wy.x = v; break; case 3: wf.x = v; break;
             case 4: wf.y = v; break; case 5: wr.x = v; break; case 6: wr.y = v; break; case 7: wy.y = v; break;
-            case 8: xy.x = v; break; case 9: xy.y = v; break; case 10: axy.x = v; break; default: axy.y = v; break;
+            case 8: xy.x = v; break; case 9: xy.y = v; break; case 10: axy.x = v; break; case 11: axy.y = v; break;
+            case 12: cuv.x = v; break; case 13: cuv.y = v; break; case 14: cwy.x = v; break; case 15: cwf.x = v; break;
+            case 16: cwf.y = v; break; case 17: cwr.x = v; break; case 18: cwr.y = v; break; case 19: cwy.y = v; break;
+            case 20: cxy.x = v; break; default: cxy.y = v; break;
             }
         }
     };
-    template <bool K2, bool CS, int PRE = 0, int FITSRC = 1>      // FITSRC: fp64 only (the packed step carries four fits)
+    // COMP: the state update s <- s + h/6 acc as a compensated (Kahan) sum per pair -- y = h/6 acc - c, t = s + y,
+    // c = (t - s) - y, s = t: what the addition rounds away is carried in c and given back at the next step (three
+    // more packed instructions per pair).  At |x| ~ 100 m the plain sum loses 4e-6 m per step to rounding; this is
+    // BASELINE's "fp32 max-abs state error".
+    template <bool K2, bool CS, int PRE = 0, int FITSRC = 1, bool COMP = false>   // FITSRC: fp64 only
     __device__ __forceinline__ void advance_state(const DevParams<float> &P, State &X, const float delta[4],
                                                   const float tq[4], const float mu[4], float h, float sd0 = 0.0f,
                                                   float cd0 = 1.0f) const
@@ -628,8 +639,20 @@ struct StepEngine<float> {
         // normal path falls through -- the SAFE redo overwrites the lanes that left the FAST range.  (Committing only
         // after the test, with the update in an else-branch, put a second TAKEN branch on the normal path: a lone wave
         // pays tens of cycles for each.  The allocator copies the packed state once per step either way.)
-        f2 uv = fma2(h6, A.uv, S.uv), wy = fma2(h6, A.wy, S.wy), wf = fma2(h6, A.wf, S.wf), wr = fma2(h6, A.wr, S.wr),
-           xy = fma2(h6, A.xy, S.xy);
+        f2 uv, wy, wf, wr, xy;
+        if (COMP) {
+#define VDYN_KAHAN(f)                                      \
+    {                                                      \
+        const f2 y_ = fma2(h6, A.f, -X.c##f);              \
+        f = S.f + y_;                                      \
+        X.c##f = (f - S.f) - y_;                           \
+    }
+            VDYN_KAHAN(uv) VDYN_KAHAN(wy) VDYN_KAHAN(wf) VDYN_KAHAN(wr) VDYN_KAHAN(xy)
+#undef VDYN_KAHAN
+        } else {
+            uv = fma2(h6, A.uv, S.uv); wy = fma2(h6, A.wy, S.wy); wf = fma2(h6, A.wf, S.wf); wr = fma2(h6, A.wr, S.wr);
+            xy = fma2(h6, A.xy, S.xy);
+        }
         if (__builtin_expect(__any(!ok) != 0, 0)) {
             if (!ok) {
                 float s[10], sn[10], axn, ayn;
@@ -641,6 +664,7 @@ struct StepEngine<float> {
                 uv = f2{sn[0], sn[1]}; wy = f2{sn[2], sn[7]}; wf = f2{sn[3], sn[4]}; wr = f2{sn[5], sn[6]};
                 xy = f2{sn[8], sn[9]};
                 axy_n = f2{axn, ayn};
+                if (COMP) X.cuv = X.cwy = X.cwf = X.cwr = X.cxy = splat(0.0f);   // the redone step starts a fresh sum
             }
         }
         X.uv = uv; X.wy = wy; X.wf = wf; X.wr = wr; X.xy = xy;

@@ -309,11 +309,18 @@ class VehicleModel:
         ``states0 [12][N]``; ``controls [H][k][N]`` (per rollout) or, with
         ``path_id [N]``, a shared table ``[P][H][k]`` staged in LDS.
         Returns ``terminal [12][N]`` (and ``traj [H//traj_stride][12][N]`` when
-        ``traj_stride > 0``)."""
+        ``traj_stride > 0``).
+
+        fp32 only: ``states0 [22][N]`` selects the compensated state sum (include/vdyn.h,
+        VDYN_OPT_STATE_ROWS) -- rows 12..21 carry the compensation terms of rows 0..9 (zeros to start
+        with); the terminal state then has 22 rows too and continues the same sum when fed back."""
         be = _Backend(states0)
         s0 = be.inp(states0)
-        if s0.ndim != 2 or s0.shape[0] != 12:
-            raise ValueError("states0 must be [12][N]")
+        if s0.ndim != 2 or s0.shape[0] not in (12, 22):
+            raise ValueError("states0 must be [12][N] (or [22][N]: fp32 with compensation terms)")
+        rows = int(s0.shape[0])
+        if rows == 22 and be.suffix != "f32":
+            raise ValueError("the compensated state sum ([22][N] states) is an fp32 option")
         n = s0.shape[1]
         ct = be.inp(controls)
         if ct.ndim != 3:
@@ -336,12 +343,18 @@ class VehicleModel:
         if traj_stride < 0:
             raise ValueError("traj_stride must be >= 0")
         keep, mu4 = self._mu4(mu_max)
-        term = be.out(12, n)
+        term = be.out(rows, n)
         traj = be.out(H // traj_stride, 12, n) if traj_stride > 0 else None
-        self._handle(be.device_index(self.device), p).call(
-            f"vdyn_rollout_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(ct), int(k), layout,
-            _vp(pid), int(P), float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj),
-            int(traj_stride), *be.stream_args())
+        h = self._handle(be.device_index(self.device), p)
+        if rows != 12:
+            h.call("vdyn_set_option", _lib.VDYN_OPT_STATE_ROWS, rows)
+        try:
+            h.call(f"vdyn_rollout_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(ct), int(k), layout,
+                   _vp(pid), int(P), float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj),
+                   int(traj_stride), *be.stream_args())
+        finally:
+            if rows != 12:
+                h.call("vdyn_set_option", _lib.VDYN_OPT_STATE_ROWS, 12)
         del keep
         return (term, traj) if traj_stride > 0 else term
 

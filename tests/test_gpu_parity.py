@@ -208,6 +208,64 @@ def test_fp32_long_horizon_1000_steps(gpu_vm, oracle, workloads):
     print(f"\n  H = 1000: fp32 row-relative err {e:.2e}, element-wise {ee:.2e}, max-abs {np.abs(term - want).max():.2e}")
 
 
+def test_fp32_compensated_state_sum_2000_steps(gpu_vm, pkg, oracle, workloads):
+    """VDYN_OPT_STATE_ROWS = 22 (include/vdyn.h): the fp32 state update as a compensated sum, the compensation terms
+    carried in rows 12..21 of the state.  BASELINE's second metric is the fp32 max-abs state error; the plain sum is
+    at 4e-4 after 200 steps and 9e-4 after 1000, rounding of x, y ~ 100 m and of the wheel speeds.  Compensated, a
+    2000-step rollout stays within 1e-4; a rollout split 700 + 1300 equals the whole bit for bit (the terminal state
+    carries the sum on); shared-table and per-rollout controls agree bit for bit; host and device pointers agree;
+    trajectories keep 12 rows; fp64 and diagnostics refuse the option."""
+    import torch
+    n, H, dt = 4096, 2000, 1e-3
+    s0, tab, pid = workloads.config3(n, H, np.float32)
+    vm = gpu_vm(dt)
+    s22 = np.concatenate([s0, np.zeros((10, n), np.float32)])
+    term = vm.rollout(s22, tab, path_id=pid)
+    assert term.shape == (22, n) and term.dtype == np.float32
+    want = oracle.rollout(oracle.default_params(), s0.astype(np.float64), tab.astype(np.float64), dt, path_id=pid,
+                          nthreads=oracle.max_threads())
+    plain = vm.rollout(s0, tab, path_id=pid)
+    e_comp, e_plain = np.abs(term[:12] - want).max(), np.abs(plain - want).max()
+    print(f"\n  H = 2000: fp32 max-abs state error {e_plain:.2e} plain, {e_comp:.2e} compensated")
+    assert e_comp <= 1e-4 and e_comp < 0.25 * e_plain
+    parity(term[:12], want, 1e-4, "compensated fp32 H = 2000")     # row-relative: 4e-5 (the plain sum: 1.2e-3 max-abs, over the bar)
+    # split horizon == one launch, bit for bit (state AND compensation rows)
+    a = vm.rollout(s22, tab[:, :700], path_id=pid)
+    b = vm.rollout(a, np.ascontiguousarray(tab[:, 700:]), path_id=pid)
+    assert np.array_equal(b, term)
+    # per-rollout controls (global loads) == LDS-shared table; k = 12 controls; device pointers
+    m = 777
+    ctrl = workloads.expand_shared_controls(tab[:, :60], pid[:m])
+    t_sh = vm.rollout(s22[:, :m], np.ascontiguousarray(tab[:, :60]), path_id=pid[:m])
+    assert np.array_equal(vm.rollout(np.ascontiguousarray(s22[:, :m]), ctrl), t_sh)
+    c12 = np.zeros((60, 12, m), np.float32)
+    c12[:, 0] = c12[:, 1] = ctrl[:, 0]
+    c12[:, 4:8] = ctrl[:, 1][:, None]
+    c12[:, 8:12] = 1.0
+    r12 = vm.rollout(np.ascontiguousarray(s22[:, :m]), c12)               # k = 12: four steering angles, rear ones rotated by 0
+    assert r12.shape == (22, m) and np.abs(r12[:12] - t_sh[:12]).max() <= 1e-4
+    dev = torch.device("cuda:0")
+    t_dev, traj = vm.rollout(torch.from_numpy(np.ascontiguousarray(s22[:, :m])).to(dev), torch.from_numpy(ctrl).to(dev),
+                             traj_stride=20)
+    assert np.array_equal(t_dev.cpu().numpy(), t_sh) and tuple(traj.shape) == (3, 12, m)
+    assert np.array_equal(traj[-1].cpu().numpy(), t_sh[:12])
+    # the default path is untouched by the option having been used on this handle
+    assert np.array_equal(vm.rollout(s0, tab, path_id=pid), plain)
+    with pytest.raises(ValueError):
+        vm.rollout(s22.astype(np.float64), tab.astype(np.float64), path_id=pid)
+    with pytest.raises(ValueError):
+        vm.rollout(s22[:13], tab, path_id=pid)
+    h = vm._handle(0)
+    h.call("vdyn_set_option", pkg._lib.VDYN_OPT_STATE_ROWS, 22)
+    try:
+        with pytest.raises(pkg.VdynError):                       # fp64 entry point with 22 rows
+            vm.rollout(s0.astype(np.float64), tab.astype(np.float64), path_id=pid)
+    finally:
+        h.call("vdyn_set_option", pkg._lib.VDYN_OPT_STATE_ROWS, 12)
+    with pytest.raises(pkg.VdynError):
+        h.call("vdyn_set_option", pkg._lib.VDYN_OPT_STATE_ROWS, 17)
+
+
 def test_step_chain_equals_rollout_and_traj(gpu_vm, workloads):
     s0, ctrl = workloads.config2(16, 12)
     vm = gpu_vm(1e-3)
