@@ -149,6 +149,7 @@ struct Waypoints {
     int ss, bs;       // element strides: 1 for a table staged in LDS; the number of tables when the
                       // auxiliary arrays live in global memory TRANSPOSED ([i][P], [b][4][P]), so that
                       // the lanes of a wave -- vehicles with consecutive tables -- read neighbouring words
+    T per = T(0);     // SOA, fp32: waypoints per metre of this lane's table, (W - 1) / cum[W - 1] (the lookahead's first guess)
     int yo = 1;       // SOA: offset of the y row
     // SOA: both levels of circles are rows too -- centre x at bounds[b] / sub[j], centre y `bo` / `so` elements further,
     // the (inflated) radius twice that; rows are 16-byte aligned and padded with centre x = +inf (never reached) to
@@ -577,34 +578,56 @@ __device__ __forceinline__ void build_closed_loop_lds(T *__restrict__ lds, const
 // so rounding can only clear a bit (when in doubt, scan).  fp32: two circles per packed instruction, six per pair, and
 // one v_alignbit_b32 per circle shifts the sign of s into the mask: 4 VALU instructions per circle (15 in the scalar
 // form with compares and selects, which was a quarter of a controller update).
-__device__ __forceinline__ unsigned circle_skip8(const float *cxr, int o, int b0, float x, float y, float U)
-{
-    const vdyn_f4 *pc = reinterpret_cast<const vdyn_f4 *>(cxr + b0), *pyy = reinterpret_cast<const vdyn_f4 *>(cxr + b0 + o),
-                  *pr = reinterpret_cast<const vdyn_f4 *>(cxr + b0 + 2 * o);
-    const vdyn_f4 ca = pc[0], cb = pc[1], ya = pyy[0], yb = pyy[1], ra = pr[0], rb = pr[1];
-    const vdyn_f2 qx = vdyn_f2{x, x}, qy = vdyn_f2{y, y}, u2 = vdyn_f2{U, U};
-    const vdyn_f2 cx[4] = {ca.xy, ca.zw, cb.xy, cb.zw}, cy[4] = {ya.xy, ya.zw, yb.xy, yb.zw}, rr[4] = {ra.xy, ra.zw, rb.xy, rb.zw};
-    unsigned m = 0u;
-#pragma unroll
-    for (int k = 3; k >= 0; --k) {                      // last circle first: alignbit pushes earlier ones to higher bits
-        const vdyn_f2 ex = cx[k] - qx, ey = cy[k] - qy, reach = rr[k] + u2;
-        vdyn_f2 sgn = __builtin_elementwise_fma(-ex, ex, reach * reach);
-        sgn = __builtin_elementwise_fma(-ey, ey, sgn);
-        m = __builtin_amdgcn_alignbit(m, __float_as_uint(sgn.y), 31);
-        m = __builtin_amdgcn_alignbit(m, __float_as_uint(sgn.x), 31);
+template <typename T> struct Circles8;
+template <> struct Circles8<float> {
+    vdyn_f4 ca, cb, ya, yb, ra, rb;
+    __device__ __forceinline__ void load(const float *cxr, int o, int b0)
+    {
+        const vdyn_f4 *pc = reinterpret_cast<const vdyn_f4 *>(cxr + b0), *pyy = reinterpret_cast<const vdyn_f4 *>(cxr + b0 + o),
+                      *pr = reinterpret_cast<const vdyn_f4 *>(cxr + b0 + 2 * o);
+        ca = pc[0]; cb = pc[1]; ya = pyy[0]; yb = pyy[1]; ra = pr[0]; rb = pr[1];
     }
-    return m;     // circle b0 + j at bit j (j = 7 was pushed first)
-}
-__device__ __forceinline__ unsigned circle_skip8(const double *cxr, int o, int b0, double x, double y, double U)
-{
-    unsigned m = 0u;
+    __device__ __forceinline__ unsigned skip(float x, float y, float U) const
+    {
+        const vdyn_f2 qx = vdyn_f2{x, x}, qy = vdyn_f2{y, y}, u2 = vdyn_f2{U, U};
+        const vdyn_f2 cx[4] = {ca.xy, ca.zw, cb.xy, cb.zw}, cy[4] = {ya.xy, ya.zw, yb.xy, yb.zw}, rr[4] = {ra.xy, ra.zw, rb.xy, rb.zw};
+        unsigned m = 0u;
 #pragma unroll
-    for (int j = 7; j >= 0; --j) {
-        const double ex = cxr[b0 + j] - x, ey = cxr[b0 + j + o] - y, reach = cxr[b0 + j + 2 * o] + U;
-        const double sgn = ::fma(-ey, ey, ::fma(-ex, ex, reach * reach));
-        m = (m << 1) | (unsigned)(__double2hiint(sgn) >> 31 & 1);
+        for (int k = 3; k >= 0; --k) {                      // last circle first: alignbit pushes earlier ones to higher bits
+            const vdyn_f2 ex = cx[k] - qx, ey = cy[k] - qy, reach = rr[k] + u2;
+            vdyn_f2 sgn = __builtin_elementwise_fma(-ex, ex, reach * reach);
+            sgn = __builtin_elementwise_fma(-ey, ey, sgn);
+            m = __builtin_amdgcn_alignbit(m, __float_as_uint(sgn.y), 31);
+            m = __builtin_amdgcn_alignbit(m, __float_as_uint(sgn.x), 31);
+        }
+        return m;     // circle b0 + j at bit j (j = 7 was pushed first)
     }
-    return m;
+};
+template <> struct Circles8<double> {
+    double cx[8], cy[8], rr[8];
+    __device__ __forceinline__ void load(const double *cxr, int o, int b0)
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cx[j] = cxr[b0 + j]; cy[j] = cxr[b0 + j + o]; rr[j] = cxr[b0 + j + 2 * o]; }
+    }
+    __device__ __forceinline__ unsigned skip(double x, double y, double U) const
+    {
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const double ex = cx[j] - x, ey = cy[j] - y, reach = rr[j] + U;
+            const double sgn = ::fma(-ey, ey, ::fma(-ex, ex, reach * reach));
+            m = (m << 1) | (unsigned)(__double2hiint(sgn) >> 31 & 1);
+        }
+        return m;
+    }
+};
+template <typename T>
+__device__ __forceinline__ unsigned circle_skip8(const T *cxr, int o, int b0, T x, T y, T U)
+{
+    Circles8<T> c;
+    c.load(cxr, o, b0);
+    return c.skip(x, y, U);
 }
 
 // The scan of nearest_in_range<T, false> over the sub-blocks named by `mask` (bit j = sub-block sb0 + j, visited in
@@ -700,6 +723,13 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const WP &wp, T x, T y, 
     T U = T(INFINITY);
     PhaseClock pc;
     VDYN_PHASE_START(pc);
+    // LDS image: the first sixteen 32-waypoint circles are on their way before the bound they will be tested against
+    // is known (their reads do not depend on it; one LDS round trip less on the update's critical path)
+    Circles8<T> first0, first1;
+    if constexpr (WP::kSoa && !EXACT) {
+        first0.load(wp.bounds, wp.bo, 0);
+        first1.load(wp.bounds, wp.bo, kChunk);
+    }
     const bool hinted = __all(hint >= 0) != 0;                   // wave-uniform: every lane brought a hint
     if (hinted) {
         const int last = wp.W - 1;
@@ -736,9 +766,13 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const WP &wp, T x, T y, 
         const bool bounded = U < T(INFINITY) && x == x && y == y;        // no bound / NaN query: everything is a candidate
         for (int g0 = 0; g0 < wp.nbu; g0 += 32) {
             unsigned skip = 0u;
-            for (int c = 0; c < min(32, wp.nbu - g0); c += 2 * kChunk)   // two chunks per trip: twelve reads in flight
-                skip |= (circle_skip8(wp.bounds, wp.bo, g0 + c, x, y, U) |
-                         circle_skip8(wp.bounds, wp.bo, g0 + c + kChunk, x, y, U) << kChunk) << c;
+            for (int c = 0; c < min(32, wp.nbu - g0); c += 2 * kChunk) { // two chunks per trip: twelve reads in flight
+                if (g0 + c == 0)
+                    skip |= first0.skip(x, y, U) | first1.skip(x, y, U) << kChunk;
+                else
+                    skip |= (circle_skip8(wp.bounds, wp.bo, g0 + c, x, y, U) |
+                             circle_skip8(wp.bounds, wp.bo, g0 + c + kChunk, x, y, U) << kChunk) << c;
+            }
             unsigned need = bounded ? ~skip : ~0u;
             const int valid = nb - g0;                                    // blocks of THIS lane's table in the group
             need &= valid >= 32 ? ~0u : ((1u << max(valid, 0)) - 1u);
@@ -831,9 +865,10 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
         const int last = wp.W - 1;
         if (total < G.lookahead && best_i < last) {
             const T target = wp.seg_at(best_i) + (G.lookahead - total);
-            const T span = wp.seg_at(last);
             int lo = best_i, hi = last;                          // invariant: cum[lo] < target; answer in (lo, hi]
-            const T per = (T)last / span;                         // waypoints per metre (inf / NaN: the bisection decides)
+            // waypoints per metre (inf / NaN: the bisection decides); the LDS image keeps it per lane, so that the
+            // window below is read together with cum[best_i] instead of after cum[last]
+            const T per = WP::kSoa ? wp.per : (T)last / wp.seg_at(last);
             T gf = (T)best_i + (G.lookahead - total) * per;
             gf = gf < (T)(best_i + 1) ? (T)(best_i + 1) : gf;
             gf = gf > (T)last ? (T)last : gf;                     // NaN stays NaN -> int conversion clamps below

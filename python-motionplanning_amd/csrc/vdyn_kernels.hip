@@ -916,6 +916,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     w.nsbu = LL.nsbu;
     w.ss = w.bs = WPLDS ? 1 : Pn;
     w.W = min(max(wcount[pid], 1), Wmax);
+    if (WPLDS && sizeof(T) == 4) w.per = (T)(w.W - 1) / w.seg_at(w.W - 1);
     StepEngine<T> eng;
     eng.template init<true, CS>(P);
 

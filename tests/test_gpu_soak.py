@@ -63,5 +63,5 @@ def test_random_envelope_against_oracle(pkg, oracle, seed):
             worst32 = max(worst32, e32 / max(f32, 1e-6))      # against what the plain-C float oracle loses on the same rollouts
     assert compared > 0.8 * total, (compared, total)
     assert worst64 <= 1e-10, worst64                          # amplification < 1e3 on rounding of a few 1e-16
-    assert worst32 <= 6.0, worst32
+    assert worst32 <= 3.0, worst32                            # measured 1.5 - 1.6 on both seeds, both kernels
     print(f"\n  seed {seed}: {compared}/{total} rollouts compared, fp64 {worst64:.1e}, fp32 {worst32:.1f} x the float oracle's own error")
