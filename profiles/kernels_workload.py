@@ -62,7 +62,8 @@ def build(case, pkg, torch, dev):
         E, C, H = 1024, 512, 50
         ego, cand, goal = (torch.from_numpy(a).to(dev) for a in W.config5(E, C, H))
         return (lambda: vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA)), dict(
-            kernel="mpc_argmin_kernel<float, true>", steps_per_lane=H, vehicle_steps=E * C * H,
+            # egos on the lanes: a wave = 64 egos x a chunk of KC = 4 candidates (launch_mpc_argmin), 4 x 50 steps per lane
+            kernel="mpc_argmin_lanes_kernel<float, true>", steps_per_lane=4 * H, vehicle_steps=E * C * H,
             algo_bytes=(12 + 2 + 2) * 4 * E + cand.numel() * 4, dynamic_lds_bytes=0)
     if case in ("closed_loop", "closed_loop_datalog"):
         n = 65536

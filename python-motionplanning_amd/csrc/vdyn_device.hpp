@@ -120,10 +120,7 @@ __device__ __forceinline__ void pin_tire_fit(DevParams<float> &) {}
 // was meant to hide behind, and deeper prefetch does not fit the scalar file.  LDS reads land in VGPRs, of which the
 // step has a hundred to spare once the pinned set of round 2 is gone, so the compiler runs them several degrees ahead.
 typedef double vdyn_d2v __attribute__((ext_vector_type(2)));
-#ifndef VDYN_FIT_KG
-#define VDYN_FIT_KG 2
-#define VDYN_FIT_AHEAD 3
-#endif
+template <int kG = 2, int kAhead = 3>     // 2 / 3: 0.558 ms on configs[1] (4 / 1: 0.570, 2 / 6: 0.574, 1 / 6: 0.584)
 __device__ __forceinline__ void fit_horner4_lds(const double cc[4], double g[4])
 {
     // Groups of kG degrees (2 kG 16-byte reads, 8 kG VGPRs), kAhead groups read ahead of the one being evaluated: a
@@ -132,7 +129,7 @@ __device__ __forceinline__ void fit_horner4_lds(const double cc[4], double g[4])
     // once, and the 152 registers they fill push the step into scratch.
     typedef const vdyn_d2v __attribute__((address_space(3))) *lds_ptr;     // stays an LDS address (32 bits), never a flat one
     const lds_ptr t0 = (lds_ptr)fit_table_lds();
-    constexpr int kG = VDYN_FIT_KG, kAhead = VDYN_FIT_AHEAD, kSlots = kAhead + 1;
+    constexpr int kSlots = kAhead + 1;
     constexpr int kRest = kTireFitDeg64 + 1 - 2;                       // degrees 2 .. 18
     constexpr int kGroups = kRest / kG;                                // the last group takes the remainder too
     constexpr int kLast = kRest - (kGroups - 1) * kG;
@@ -449,7 +446,7 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
             syb[i] = -vy * abs_t(rvxB);
             cc[i] = M::rsqrt(fma_t(sxb[i], sxb[i], fma_t(syb[i], syb[i], T(1))));
         }
-        fit_horner4_lds(cc, g);
+        fit_horner4_lds<2, DIAG ? 1 : 3>(cc, g);      // the diagnostics step has few registers for reads in flight
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool steered = i < 2 || !K2;

@@ -872,7 +872,13 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
                    T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log,
                    T *__restrict__ datalog, const T *__restrict__ aux)
 {
-    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
+    // fp64 with the DataLog: the step that also averages the 28 diagnostics has no 38 VGPRs left for a pinned fit (it
+    // spilled 250-380 bytes per lane to scratch) -- it reads the table from LDS instead (fit_horner4_lds)
+    constexpr bool kFitLds = DATALOG && sizeof(T) == 8;
+    if (CS) {                           // only the fitted chain reads them
+        if (kFitLds) stage_tire_fit(P);
+        else pin_tire_fit(P);
+    }
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS image (ClosedLoopLds, vdyn_controls.hpp): x rows, y rows (padded to whole 8-waypoint sub-blocks, 16-byte
     // aligned, rows of different paths 4 banks apart: lanes of one wave follow different paths and read the same
@@ -972,7 +978,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
             T s[10], ax = X.get(10), ay = X.get(11);
 #pragma unroll
             for (int i = 0; i < 10; ++i) s[i] = X.get(i);
-            eng.template advance_diag<true, CS>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
+            eng.template advance_diag<true, CS, kFitLds ? 2 : 1>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
 #pragma unroll
             for (int i = 0; i < 10; ++i) X.set(i, s[i]);
             X.set(10, ax);

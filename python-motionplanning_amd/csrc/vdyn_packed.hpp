@@ -563,11 +563,11 @@ struct StepEngine {
         rk4_advance<T, K2, false, CS, PRE, 1>(P, s, ax, ay, delta, tq, mu, h, nullptr, nullptr, sd0, cd0);
     }
     // the same step with state_dot [10] and the averaged outputs [18] (vehicle_model.py:440-441)
-    template <bool K2, bool CS>
+    template <bool K2, bool CS, int FITSRC = 1>
     __device__ __forceinline__ void advance_diag(const DevParams<T> &P, T s[10], T &ax, T &ay, const T delta[4],
                                                  const T tq[4], const T mu[4], T h, T sd[10], Outputs18<T> &o) const
     {
-        rk4_advance<T, K2, true, CS>(P, s, ax, ay, delta, tq, mu, h, sd, &o);
+        rk4_advance<T, K2, true, CS, 0, FITSRC>(P, s, ax, ay, delta, tq, mu, h, sd, &o);
     }
 };
 
@@ -686,7 +686,7 @@ struct StepEngine<float> {
         ax = X.axy.x;
         ay = X.axy.y;
     }
-    template <bool K2, bool CS>
+    template <bool K2, bool CS, int FITSRC = 1>                   // FITSRC: fp64 only
     __device__ __forceinline__ void advance_diag(const DevParams<float> &P, float s[10], float &ax, float &ay,
                                                  const float delta[4], const float tq[4], const float mu[4],
                                                  float h, float sd[10], Outputs18<float> &o) const
