@@ -59,7 +59,14 @@ class OracleBackedHandle:
             else:
                 _view(term, 12 * n)[:] = out.ravel()
         elif name == "vdyn_set_option":
-            pass
+            self.options = getattr(self, "options", []) + [tuple(a)]
+        elif name == "vdyn_rollout_f32_host":
+            # records the marshalling only: rows of the state arrays follow the option set just before
+            n, H, s0, ct, k, layout, pid, P, dt, mu4, term, traj, stride = a
+            self.rollout_rows = [v for o, v in self.options if o == 2][-1] if getattr(self, "options", None) else 12
+            rows = self.rollout_rows
+            src = np.ctypeslib.as_array((C.c_float * (rows * n)).from_address(s0.value)).reshape(rows, n)
+            np.ctypeslib.as_array((C.c_float * (rows * n)).from_address(term.value)).reshape(rows, n)[:] = src + 1.0
         else:
             raise AssertionError(f"unexpected ABI call {name}")
 
@@ -137,6 +144,40 @@ def test_rollout_spiral_host_marshalling(vm_mock, oracle, workloads):
                 lambda: vm.rollout_spiral(s0, sp, -1), lambda: vm.rollout_spiral(s0, sp.reshape(7, 3, 3)[:, :, :2], 5)):
         with pytest.raises(ValueError):
             bad()
+
+
+def test_rollout_state_rows_option_marshalling(vm_mock, pkg, workloads):
+    """VehicleModel.rollout with a [22][N] fp32 state (include/vdyn.h, VDYN_OPT_STATE_ROWS): the option is set to 22
+    for that call and back to 12 after it -- also when the call raises --, the terminal state has 22 rows; fp64
+    and other row counts are refused before any ABI call."""
+    vm, h = vm_mock
+    lib = pkg._lib
+    s0, tab, pid = workloads.config3(70, 6, np.float32)
+    s22 = np.concatenate([s0, np.zeros((10, 70), np.float32)])
+    ctrl = workloads.expand_shared_controls(tab, pid)
+    term = vm.rollout(s22, ctrl)
+    assert term.shape == (22, 70) and term.dtype == np.float32 and np.array_equal(term, s22 + 1.0)
+    assert h.options == [(lib.VDYN_OPT_STATE_ROWS, 22), (lib.VDYN_OPT_STATE_ROWS, 12)] and h.rollout_rows == 22
+    h.options = []
+    term = vm.rollout(s0, ctrl)
+    assert term.shape == (12, 70) and h.options == [] and h.rollout_rows == 12
+    n_calls = len(h.calls)
+    for bad in (lambda: vm.rollout(s22.astype(np.float64), ctrl.astype(np.float64)),
+                lambda: vm.rollout(s22[:17], ctrl), lambda: vm.rollout(s22[:11], ctrl)):
+        with pytest.raises(ValueError):
+            bad()
+    assert len(h.calls) == n_calls, "refused before any ABI call"
+
+    def boom(name, *a):
+        if name.startswith("vdyn_rollout"):
+            raise pkg.VdynError(-1, "simulated")
+        return OracleBackedHandle.call(h, name, *a)
+    h.options = []
+    h.call, orig = boom, h.call
+    with pytest.raises(pkg.VdynError):
+        vm.rollout(s22, ctrl)
+    h.call = orig
+    assert h.options[-1] == (lib.VDYN_OPT_STATE_ROWS, 12), "the option is restored when the call fails"
 
 
 def test_interpolate_waypoints_out_argument_is_validated(vm_mock):
