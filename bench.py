@@ -113,7 +113,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(W, gpu_terminal=None):
+def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None):
     """The oracle (oracle/, the checker -- never the product) timed on this host:
     kind 'port'.  Bounded sample of the bench workload, sized for ~10-30 core-seconds.
     ``gpu_terminal`` ([12][N] fp32, the bench kernel's own output): its error against the fp64
@@ -151,6 +151,11 @@ def cpu_baseline(W, gpu_terminal=None):
         err = {"max_abs": float(d.max()), "max_abs_row": names[int(d.max(axis=1).argmax())],
                "max_rel_to_row_scale": float((d / scale).max()), "tolerance_rel": 1e-3,
                "against": "fp64 C oracle, all 65536 rollouts x 200 steps, terminal [12][N]"}
+        if gpu_terminal_comp is not None:
+            # the same launch with the compensated state sum (VDYN_OPT_STATE_ROWS = 22: include/vdyn.h)
+            dc = np.abs(gpu_terminal_comp.astype(np.float64) - ref)
+            err["compensated_state_sum"] = {"max_abs": float(dc.max()), "max_abs_row": names[int(dc.max(axis=1).argmax())],
+                                            "max_rel_to_row_scale": float((dc / scale).max())}
     return {
         "fp32_state_error": err,
         "value": reps * N_PER_GPU * HORIZON / t_all, "unit": "vehicle-steps/s", "cores": threads,
@@ -457,7 +462,11 @@ def run(args, compute_factory=None):
             out["extra"] = extra_configs(cp.vm, W, torch, dev, s0, tab, pid)
         if world == 1 and on_gpu and not args.no_cpu_baseline:
             full_size = not args.strong and per_gpu == N_PER_GPU and H == HORIZON
-            cb = cpu_baseline(W, term.cpu().numpy() if full_size else None)
+            term_c = None
+            if full_size:
+                s22 = torch.cat([s0, torch.zeros((10, s0.shape[1]), dtype=s0.dtype, device=dev)])
+                term_c = cp.vm.rollout(s22, tabd, path_id=pid)[:12].cpu().numpy()
+            cb = cpu_baseline(W, term.cpu().numpy() if full_size else None, term_c)
             err = cb.pop("fp32_state_error")
             if err is not None:
                 out["fp32_state_error"] = err
@@ -501,6 +510,13 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
         "hbm_GBs_algorithmic": BYTES_PER_STEP_PER_ROLLOUT * n / t / 1e9,
         "hbm_frac": BYTES_PER_STEP_PER_ROLLOUT * n / t / 1e9 / HBM_PEAK_GBS}
     del ctrl
+    # the headline launch with the compensated state sum: [22][N] states (include/vdyn.h, VDYN_OPT_STATE_ROWS)
+    s22 = torch.cat([s0, torch.zeros((10, s0.shape[1]), dtype=s0.dtype, device=dev)])
+    tab_c = torch.from_numpy(tab).to(dev)
+    vm.rollout(s22, tab_c, path_id=pid)
+    t = timed_launches(lambda: vm.rollout(s22, tab_c, path_id=pid), 5, torch)
+    ex["compensated_state_sum_65536x200_f32"] = {"steps_per_s": n / t, "kernel_ms": t * 1e3, "state_rows": 22}
+    del s22, tab_c
     s2, c2 = W.config2(64, HORIZON)
     s2d, c2d = torch.from_numpy(s2).to(dev), torch.from_numpy(c2).to(dev)
     vm.rollout(s2d, c2d)
@@ -510,6 +526,16 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     vmq.rollout(s2d, c2d)
     t = timed_launches(lambda: vmq.rollout(s2d, c2d), 5, torch)
     ex["config2_4096x200_f64_wheel_parallel"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
+    # the same with a different shape factor on the rear axle (the under / oversteer experiment the reference sketches,
+    # vehicle_model.py:237-242): fp64 fits per wheel -- from LDS in the lane kernel, in registers in the wheel-parallel one
+    import importlib as _il
+    pw = _il.import_module("python-motionplanning_amd").VehicleParameters()
+    pw.CRL = pw.CRR = 1.3
+    for name, lanes in (("", 1), ("_wheel_parallel", 4)):
+        vmp = type(vm)(2.906, np.deg2rad(30), DT, params=pw, device=vm.device, lanes_per_rollout=lanes)
+        vmp.rollout(s2d, c2d)
+        t = timed_launches(lambda: vmp.rollout(s2d, c2d), 5, torch)
+        ex[f"config2_4096x200_f64_rear_C_1.3{name}"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
     # the same launch with the steering table scaled by 8 (+-27 deg) and every fourth ego's wheels locked: tires
     # from zero slip to far past the friction peak (B s up to ~20).  The step has no data-dependent path -- the
     # fitted shape function covers every slip with one polynomial -- so this must cost what the headline costs.
