@@ -249,7 +249,10 @@ int vdyn_mpc_argmin_f64_host(VdynHandle *h, int32_t E, int32_t C, int32_t H, con
  * prev_vel (PID memory, drive.py:50,52,131-134), target_vel (drive.py:51), delta and torque
  * (the held commands, drive.py:138,131).  Waypoints: wp [P][Wmax][2] = (x, y) rows of the
  * lists LateralTrackerObj.update_waypoints receives (local_planner.py:419), wcount [P] valid
- * rows per table, path_id [n] the table each vehicle tracks.                                 */
+ * rows per table, path_id [n] the table each vehicle tracks.  fp32: the lookahead walk runs on the
+ * cumulative arc length of a table, so the first wcount rows of an fp32 table must be finite (a NaN
+ * row would poison the sums behind it; the reference -- and the fp64 entry points -- only meet such
+ * a row when the walk crosses it).                                                            */
 
 /* Gains of Car.__init__ (drive.py:56,71-85): k=100, k_soft=1, max_steer=30 deg, lookahead=5,
  * deadband=0.01 (stanley_controller.py:46-47), kp=1000, ki=100, kd=0, filter 1e-5/(2*0.001). */

@@ -43,10 +43,13 @@ struct PhaseClock {
 };
 #define VDYN_PHASE_START(pc) (pc).start()
 #define VDYN_PHASE_LAP(pc, i) (pc).lap(i)
+__device__ unsigned long long g_vdyn_event[4];           // counted over ALL waves (one add per wave and event)
+#define VDYN_EVENT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_vdyn_event[i], 1ull); } while (0)
 #else
 struct PhaseClock {};
 #define VDYN_PHASE_START(pc) (void)(pc)
 #define VDYN_PHASE_LAP(pc, i) (void)(pc)
+#define VDYN_EVENT(i) (void)0
 #endif
 
 template <typename T>
@@ -688,6 +691,54 @@ __device__ __forceinline__ void nearest_in_subblocks(const WP &wp, int sb0, unsi
     ambiguous = best < inf && (close > 1 || second <= thr);
 }
 
+// The exact form of the same scan, for the waves in which some lane's candidates tied (1.4 % of the searches of the
+// bench workload): the reference compares ROUNDED ROOTS with a strict '<' (stanley_controller.py:60-66), so the
+// answer is the first waypoint whose rounded distance equals the smallest rounded distance -- taken here over the
+// masked sub-blocks only (everything else is farther than the bound, no tie possible), eight IEEE square roots per
+// trip.  ~1000 cycles.  (Round 2 sent such a wave back through the whole pruned search in its sequential exact form,
+// ≈10 000 cycles; with one wave per SIMD the kernel ends with its slowest wave, and the unluckiest of 1024 waves
+// met three or four ties in 20 updates: 35 us between the average wave's end and the kernel's.)
+template <typename T, typename WP>
+__device__ __forceinline__ void nearest_in_subblocks_exact(const WP &wp, int sb0, unsigned mask, T x, T y, T &best_d2,
+                                                           int &best_i)
+{
+    using L = Lib<T>;
+    const T inf = T(INFINITY);
+    T best = inf;                                                     // smallest rounded root so far
+    int best_sb = -1;
+    while (__any(mask != 0u)) {
+        const bool act = mask != 0u;
+        const int sb = sb0 + (act ? __builtin_ctz(mask) : 0);
+        mask &= mask - 1u;
+        Block8<T> A;
+        A.load(wp.base, wp.yo, sb * kSubBlock);
+        T d2[8], r[8];
+        A.d2(x, y, d2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = L::sqrt(d2[k]);
+        T m = min_t(min_t(min_t(r[0], r[1]), min_t(r[2], r[3])), min_t(min_t(r[4], r[5]), min_t(r[6], r[7])));
+        m = act ? m : inf;
+        const bool better = m < best;                                 // strict: an equal root in a later sub-block loses
+        best = better ? m : best;
+        best_sb = better ? sb : best_sb;
+    }
+    const int sbr = best_sb < 0 ? sb0 : best_sb;
+    Block8<T> win;
+    win.load(wp.base, wp.yo, sbr * kSubBlock);
+    T d2[8];
+    win.d2(x, y, d2);
+    int k_first = 0;
+    T d2_first = inf;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        const bool hit = L::sqrt(d2[k]) == best;
+        k_first = hit ? k : k_first;
+        d2_first = hit ? d2[k] : d2_first;
+    }
+    best_d2 = best_sb < 0 ? inf : d2_first;
+    best_i = best_sb < 0 ? 0 : sbr * kSubBlock + k_first;
+}
+
 // The same global search, exactly, with most of the table skipped.  Every 32 consecutive waypoints
 // carry a bounding circle (centre c, radius r >= every member's distance to c), so block b holds a
 // point within |q - c_b| + r_b of the query q and none nearer than |q - c_b| - r_b.
@@ -794,6 +845,11 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const WP &wp, T x, T y, 
             mask &= nsub >= 32 ? ~0u : ((1u << nsub) - 1u);
             VDYN_PHASE_LAP(pc, 2);      // 8-waypoint circles
             nearest_in_subblocks<T>(wp, sb0, mask, x, y, best_d2, best_i, ambiguous);
+            if (__builtin_expect(__any(ambiguous) != 0, 0)) {          // wave-uniform; settles every lane of the wave
+                VDYN_EVENT(1);
+                nearest_in_subblocks_exact<T>(wp, sb0, mask, x, y, best_d2, best_i);
+                ambiguous = false;
+            }
             VDYN_PHASE_LAP(pc, 3);      // block scan + resolve
             return;
         }
@@ -835,7 +891,9 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
         const int hint = near_io != nullptr ? *near_io : -1;
         const int adv = adv_io != nullptr ? *adv_io : 0;
         nearest_waypoint_pruned<T, false>(wp, x, y, best_d2, best_i, amb, hint, adv);
+        VDYN_EVENT(0);
         if (__builtin_expect(__any(amb) != 0, 0)) {      // wave-uniform, practically never taken
+            VDYN_EVENT(2);
             if (amb) nearest_waypoint_pruned<T, true>(wp, x, y, best_d2, best_i, amb, hint, adv);
         }
         if (near_io != nullptr) {

@@ -73,3 +73,84 @@ def test_fp32_closed_loop_indices_follow_fp64(gpu_vm, pkg, oracle, workloads):
     didx = np.abs(log[::10, 14] - olog[::10, 14])
     assert didx.max() <= 1 and (didx != 0).mean() <= 0.02
     assert np.abs(log[:, 12] - olog[:, 12]).max() <= 2e-3        # filtered steering command
+
+
+def _adversarial_tables():
+    """Six waypoint tables (Wmax = 203: odd, so the LDS image is staged pair by pair) built to break a pruned
+    nearest-waypoint search: a figure-eight that crosses itself, a path with every waypoint twice (exact ties between
+    neighbours), tables of 1 and 7 points, a line with a NaN waypoint, a closed circle whose last point equals its
+    first (a tie between index 0 and the last index)."""
+    Wmax = 203
+    wp = np.zeros((6, Wmax, 2))
+    wc = np.array([203, 200, 1, 7, 150, 181], dtype=np.int32)
+    t = np.linspace(0.0, 2 * np.pi, 203)
+    wp[0, :, 0], wp[0, :, 1] = 12.0 * np.sin(t), 6.0 * np.sin(2 * t)                   # figure-eight through the origin
+    s = np.repeat(np.arange(100) * 0.05, 2)
+    wp[1, :200, 0], wp[1, :200, 1] = s, 0.02 * s * s                                   # every point twice
+    wp[2, 0] = (3.0, -1.0)
+    wp[3, :7, 0], wp[3, :7, 1] = np.arange(7) * 0.4, 0.1 * np.arange(7)
+    wp[4, :150, 0], wp[4, :150, 1] = np.arange(150) * 0.06, 1.0
+    wp[4, 3] = (np.nan, np.nan)                                                        # never the nearest; behind every vehicle
+    a = np.linspace(0.0, 2 * np.pi, 181)
+    wp[5, :181, 0], wp[5, :181, 1] = 5.0 * np.cos(a), 5.0 * np.sin(a)
+    wp[5, 180] = wp[5, 0]                      # last == first, bit for bit (sin(2 pi) is -2.4e-16, which would make the
+                                               # choice hang on the last bit of x*x + y*y: fma or not, BLAS or not)
+    wp[:, :, :][np.arange(6)[:, None] * 0 + np.arange(Wmax)[None, :] >= wc[:, None]] = 1e6   # garbage past each table's end
+    return wp, wc
+
+
+def test_closed_loop_search_on_adversarial_tables(gpu_vm, pkg, oracle):
+    """The closed loop's LDS search (two levels of bounding circles, per-lane masks, packed block scan, hinted
+    bound) on tables built to defeat it, 40 sub-steps = 4 controller updates (the first without a hint), vehicles on,
+    near, and 200 m away from their paths (the bound is then so loose that whole tables survive the circles): fp64
+    target indices and states exactly as the oracle's; chained launches == one launch; tables too big for LDS (the
+    global-memory search) give the same bits; fp32 follows within rounding."""
+    wp, wc = _adversarial_tables()
+    rng = np.random.default_rng(99)
+    n, dt, H = 1536, 1e-3, 40
+    pid = (np.arange(n) % 6).astype(np.int32)
+    k = (rng.uniform(0, 1, n) * (wc[pid] - 1)).astype(int)
+    k[pid == 4] = np.maximum(k[pid == 4], 10)
+    s0 = np.zeros((12, n))
+    s0[0] = rng.uniform(8, 25, n)
+    s0[3:7] = s0[0] / 0.308309813617345
+    far = rng.uniform(0, 1, n) < 0.05
+    s0[8] = np.nan_to_num(wp[pid, k, 0]) + rng.normal(0, 0.3, n) + 200.0 * far
+    s0[9] = np.nan_to_num(wp[pid, k, 1]) + rng.normal(0, 0.3, n)
+    s0[8, pid == 0] *= rng.uniform(0, 1, (pid == 0).sum()) < 0.5                      # half of the figure-eight's vehicles at the crossing
+    s0[9, pid == 0] *= s0[8, pid == 0] != 0
+    s0[7] = rng.uniform(-np.pi, np.pi, n)
+    c0 = np.zeros((6, n))
+    c0[2], c0[3] = s0[0], 25.0
+    vm = gpu_vm(dt)
+    cp = oracle.ctrl_params()
+    term, cs, log = vm.closed_loop(s0, c0, wp, H, wcount=wc, path_id=pid, log=True)
+    with np.errstate(all="ignore"):
+        ot, oc, olog = oracle.closed_loop(oracle.default_params(), cp, s0, c0, wp, wc, pid, dt, H, log=True, nthreads=8)
+    ok = np.isfinite(ot).all(axis=0)                                                  # the NaN table can make a walk non-finite in both
+    assert ok.mean() > 0.8
+    assert np.array_equal(log[::10, 14][:, ok], olog[::10, 14][:, ok]), "target indices must match the oracle exactly"
+    from conftest import parity
+    assert parity(term[:, ok], ot[:, ok], 1e-6) <= 1e-8
+    a, ca = vm.closed_loop(s0, c0, wp, 13, wcount=wc, path_id=pid)
+    b, cb = vm.closed_loop(a, ca, wp, 27, wcount=wc, path_id=pid, phase=13)
+    assert np.array_equal(b[:, ok], term[:, ok]) and np.array_equal(cb[:, ok], cs[:, ok])
+    big = np.full((6, 30000, 2), 1e6)                                                  # 6 x 30000 x 24 B: no LDS image
+    big[:, :203] = wp
+    t2, c2 = vm.closed_loop(s0, c0, big, H, wcount=wc, path_id=pid)
+    assert np.array_equal(t2[:, ok], term[:, ok]) and np.array_equal(c2[:, ok], cs[:, ok])
+    # fp32: same tables (203 floats per row: the scalar staging path).  Two things are the precision's, not the
+    # search's: a vehicle AT the figure-eight's crossing takes either branch (the plain-C float oracle differs from the
+    # fp64 one on 12 % of that table's updates), so fp32 is held to the FLOAT oracle; and the fp32 lookahead works on
+    # the cumulative arc length, which a NaN waypoint poisons for everything behind it (the reference -- and the fp64
+    # path -- only meet a NaN segment when the walk crosses it): fp32 tables must be finite up to wcount (include/vdyn.h).
+    with np.errstate(all="ignore"):
+        _, _, olog32 = oracle.closed_loop(oracle.default_params(), cp, s0.astype(np.float32), c0.astype(np.float32),
+                                          wp.astype(np.float32), wc, pid, dt, H, log=True, nthreads=8)
+    t32, c32, log32 = vm.closed_loop(s0.astype(np.float32), c0.astype(np.float32), wp.astype(np.float32), H, wcount=wc,
+                                     path_id=pid, log=True)
+    ok32 = ok & np.isfinite(t32).all(axis=0) & (pid != 4)
+    didx = np.abs(log32[::10, 14][:, ok32] - olog32[::10, 14][:, ok32])
+    off = (didx > 1).mean()
+    print(f"\n  adversarial tables: {ok.mean():.1%} finite in the oracle, fp32 indices more than one off the float oracle's on {off:.2%}")
+    assert off <= 0.02

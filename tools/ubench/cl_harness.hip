@@ -74,6 +74,7 @@ int main(int argc, char **argv)
 #ifdef VDYN_STAMPS
     unsigned long long zero[16] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_vdyn_phase), zero, sizeof(zero)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_vdyn_event), zero, 4 * sizeof(unsigned long long)));
 #endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -100,10 +101,11 @@ int main(int argc, char **argv)
     for (int i = 0; i < 16; ++i)
         printf("  %-16s %9.0f cycles per %s\n", names[i], (double)ph[i] / reps / (i == 7 ? H : i >= 10 ? 1 : updates),
                i == 7 ? "sub-step" : i >= 10 ? "launch" : "update");
-    {
-        unsigned long long t0 = 0;
-        (void)t0;
-    }
+    unsigned long long ev[4];
+    CK(hipMemcpyFromSymbol(ev, HIP_SYMBOL(g_vdyn_event), sizeof(ev)));
+    printf("  searches (wave-level) %llu per launch; ties settled over the masked sub-blocks %llu (%.2f %%), sent to the "
+           "sequential exact search %llu\n", ev[0] / reps, ev[1] / reps, 100.0 * (double)ev[1] / (double)(ev[0] ? ev[0] : 1),
+           ev[2] / reps);
 #endif
     return 0;
 }
