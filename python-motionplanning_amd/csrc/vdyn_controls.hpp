@@ -875,6 +875,17 @@ __device__ __forceinline__ void nearest_waypoint_pruned(const WP &wp, T x, T y, 
         if (hi < lo) { lo = 0; hi = nb - 1; }                                // nothing comparable: plain full scan
     }
     nearest_in_range<T, EXACT>(wp, lo * kWpBlock, min((hi + 1) * kWpBlock, wp.W), x, y, best_d2, best_i, ambiguous);
+    if constexpr (!EXACT) {
+        // a tie: the exact form of the scan over the SAME range (what lies outside it is farther than the bound and
+        // cannot tie) -- not, as in round 2, the whole search again from the circles on
+        if (__builtin_expect(__any(ambiguous) != 0, 0)) {
+            VDYN_EVENT(2);
+            best_d2 = T(INFINITY);
+            best_i = 0;
+            nearest_in_range<T, true>(wp, lo * kWpBlock, min((hi + 1) * kWpBlock, wp.W), x, y, best_d2, best_i, ambiguous);
+            ambiguous = false;
+        }
+    }
 }
 
 // stanley_controller.py:78-129 -> steering angle (limited), target index, crosstrack error
@@ -892,8 +903,7 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
         const int adv = adv_io != nullptr ? *adv_io : 0;
         nearest_waypoint_pruned<T, false>(wp, x, y, best_d2, best_i, amb, hint, adv);
         VDYN_EVENT(0);
-        if (__builtin_expect(__any(amb) != 0, 0)) {      // wave-uniform, practically never taken
-            VDYN_EVENT(2);
+        if (__builtin_expect(__any(amb) != 0, 0)) {      // never taken any more: the pruned search settles its own ties
             if (amb) nearest_waypoint_pruned<T, true>(wp, x, y, best_d2, best_i, amb, hint, adv);
         }
         if (near_io != nullptr) {
