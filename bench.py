@@ -181,11 +181,14 @@ def pmc_summary():
         return {}
 
 
-def counter_fields(pmc, build_id, steps_per_launch, kern_s):
+def counter_fields(pmc, build_id, steps_per_launch, kern_s, rollouts=None):
     """The counter-derived part of `roofline` -- HBM traffic per launch and the issue-slot view -- from a committed
     PMC summary, but ONLY when that summary was taken on the very code objects this process loaded
     (`build_id` = vdyn_build_id() of the library, stored in the summary by profiles/summarize.py).  Any other summary
-    (no id, another build) gives {"traffic": None, "pmc_stale": True, ...}: stale counters are never reported."""
+    (no id, another build) gives {"traffic": None, "pmc_stale": True, ...}: stale counters are never reported.
+    `traffic` is bytes per launch OF THE PROFILED LAUNCH (pmc["grid"] rollouts): a launch of another size (`rollouts`
+    given and different, e.g. --rollouts-per-gpu) reports traffic None and "pmc_shape_mismatch"; the per-step
+    instruction counts do not depend on the launch size and stay."""
     src = "profiles/pmc_summary.json (" + str(pmc.get("tag")) + ")"
     if not pmc:
         return {"traffic": None}
@@ -193,6 +196,9 @@ def counter_fields(pmc, build_id, steps_per_launch, kern_s):
         return {"traffic": None, "pmc_stale": True, "pmc_source": src,
                 "pmc_build_id": pmc.get("build_id"), "loaded_build_id": build_id}
     out = {"traffic": pmc.get("hbm_bytes_per_launch"), "pmc_stale": False, "pmc_source": src}
+    if rollouts is not None and pmc.get("grid") is not None and int(pmc["grid"]) != int(rollouts):
+        out.update({"traffic": None, "pmc_shape_mismatch": {"profiled_rollouts": int(pmc["grid"]),
+                                                            "launched_rollouts": int(rollouts)}})
     ipw = pmc.get("valu_insts_per_wave_per_rk4_step")
     if ipw:
         # issue-slot form of the same roofline: measured VALU wave-instructions per RK4 step
@@ -319,6 +325,11 @@ def run(args, compute_factory=None):
     s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
     pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
+    # the next rank's inputs, kept on the host: after the timed region this rank integrates that block itself
+    # and compares what the exchange delivered for it bit for bit (`exchange.verified`)
+    plo, phi = sh.bounds[(rank + 1) % world]
+    s0_peer = np.ascontiguousarray(s0_all[:, plo:phi]) if collective else None
+    pid_peer = pid_all[plo:phi].copy() if collective else None
     del s0_all, pid_all
     xch = D.make_exchange(args.exchange, sh, rows=12, like=s0, handle=cp.handle()) if collective else None
 
@@ -387,10 +398,16 @@ def run(args, compute_factory=None):
     gathered_ok = None
     if collective:
         # the exchanged result, checked once outside the timed region: this rank's own block came back
-        # unchanged and every block is finite
+        # unchanged, every block is finite, and the block of the NEXT rank -- data that crossed the link --
+        # equals, bit for bit, this rank's own integration of that rank's inputs (same kernel, same code
+        # object: SURVEY 8e's shard + gather identity); the verdict is the AND over all ranks
         full = xch.result()
+        peer = cp.rollout(torch.from_numpy(s0_peer).to(dev), tabd, torch.from_numpy(pid_peer).to(dev))
         gathered_ok = bool(torch.equal(full[:, lo:hi], term)) and bool(torch.isfinite(full).all()) \
-            and tuple(full.shape) == (12, n_total)
+            and tuple(full.shape) == (12, n_total) and bool(torch.equal(full[:, plo:phi], peer))
+        okt = torch.tensor([1 if gathered_ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        gathered_ok = bool(int(okt.item()))
         if args.dump_gathered:
             np.save(os.path.join(args.dump_gathered, f"gathered_rank{rank}.npy"), full.cpu().numpy())
 
@@ -418,6 +435,8 @@ def run(args, compute_factory=None):
         "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
         "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
                                                  "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok,
+                                                 "verified_how": "every rank: own block unchanged, all finite, next "
+                                                                 "rank's block == own integration of its inputs (bitwise)",
                                                  "requested": args.exchange, "fallback_reason": xch.fallback_reason},
         "config": {
             "workload": f"BASELINE configs[2]: {per_gpu} rollouts per GPU (ego r//7, lattice path r%7; whole egos per "
@@ -432,7 +451,8 @@ def run(args, compute_factory=None):
     if rank == 0:
         build_id = pkg._lib.build_id() if on_gpu else None
         out["build_id"] = build_id
-        cf = counter_fields(pmc_summary() if on_gpu else {}, build_id, steps_per_launch, kern_s)
+        cf = counter_fields(pmc_summary() if on_gpu else {}, build_id, steps_per_launch, kern_s,
+                            rollouts=n_local if H == HORIZON else -1)
         # the binding roofline of this kernel is VALU issue, priced as 850 flop per
         # vehicle-step against the fp32 vector peak
         tf = FLOP_PER_STEP * steps_per_launch / kern_s / 1e12

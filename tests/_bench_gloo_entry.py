@@ -23,11 +23,17 @@ class OracleCompute:
         self.device = torch.device("cpu")
         self.dt, self.p, self._t = dt, O.default_params(), time.perf_counter
         self.lanes = lanes_per_rollout
+        # VDYN_TEST_FLIP_RANK=r: rank r's compute returns one element one ulp off -- what a damaged transfer
+        # looks like to the ranks that receive its block (test_bench_multirank's negative case)
+        self.flip = os.environ.get("VDYN_TEST_FLIP_RANK") == os.environ.get("RANK", "0")
 
     def rollout(self, s0, tab, pid):
         t = O.rollout(self.p, s0.numpy().astype(np.float64), tab.numpy().astype(np.float64), self.dt,
                       path_id=pid.numpy(), nthreads=1)
-        return torch.from_numpy(t.astype(np.float32))
+        t = t.astype(np.float32)
+        if self.flip:
+            t[3, t.shape[1] // 2] = np.nextafter(t[3, t.shape[1] // 2], np.float32(np.inf))
+        return torch.from_numpy(t)
 
     def handle(self):
         return None

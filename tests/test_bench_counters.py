@@ -20,6 +20,15 @@ def test_counters_of_the_loaded_build_are_reported():
     assert 0.0 < cf["issue_frac"] < 1.0 and cf["pmc_source"].endswith("(rXX)")
 
 
+def test_traffic_is_only_quoted_for_the_profiled_launch_shape():
+    pmc = dict(PMC, grid=65536)
+    assert bench.counter_fields(pmc, PMC["build_id"], 65536 * 200, 0.153e-3, rollouts=65536)["traffic"] == 6.9e6
+    cf = bench.counter_fields(pmc, PMC["build_id"], 14000 * 50, 0.04e-3, rollouts=14000)
+    assert cf["traffic"] is None and cf["pmc_stale"] is False
+    assert cf["pmc_shape_mismatch"] == {"profiled_rollouts": 65536, "launched_rollouts": 14000}
+    assert cf["valu_insts_per_wave_step"] == 372.4
+
+
 def test_counters_of_another_build_are_dropped_and_flagged():
     for pmc, loaded in ((PMC, "fedcba9876543210"), ({k: v for k, v in PMC.items() if k != "build_id"}, "0123456789abcdef"),
                         (PMC, None)):

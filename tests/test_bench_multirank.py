@@ -14,12 +14,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRY = os.path.join(REPO, "tests", "_bench_gloo_entry.py")
 
 
-def _launch(tmp_path, world, extra):
+def _launch(tmp_path, world, extra, env_extra=None):
     argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-extra",
             "--no-cpu-baseline", "--horizon", "12", "--dump-gathered", str(tmp_path), *extra]
     code = ("import sys; sys.path.insert(0, %r); import bench; "
             "sys.exit(bench.spawn_ranks(%d, %r, script=%r))" % (REPO, world, argv, ENTRY))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -52,6 +53,14 @@ def test_bench_two_ranks_shard_by_whole_egos_and_gather_bitwise(tmp_path, mode, 
     for r in range(world):
         got = np.load(tmp_path / f"gathered_rank{r}.npy")
         assert got.dtype == np.float32 and np.array_equal(got, single)
+
+
+def test_one_ulp_of_difference_in_a_peer_block_is_reported_as_unverified(tmp_path):
+    """`exchange.verified` is more than "my own block came back": every rank integrates the NEXT rank's inputs itself
+    and compares the delivered block bitwise.  Rank 1 here returns one element one ulp off; rank 0 must notice, and
+    the verdict rank 0 prints is the AND over the ranks."""
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70"], env_extra={"VDYN_TEST_FLIP_RANK": "1"})
+    assert out["exchange"]["verified"] is False and "bitwise" in out["exchange"]["verified_how"]
 
 
 def test_total_rollouts_keeps_one_wave_per_simd():
