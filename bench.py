@@ -547,15 +547,21 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = timed_launches(lambda: vmq.rollout(s2d, c2d), 5, torch)
     ex["config2_4096x200_f64_wheel_parallel"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
     # the same with a different shape factor on the rear axle (the under / oversteer experiment the reference sketches,
-    # vehicle_model.py:237-242): fp64 fits per wheel -- from LDS in the lane kernel, in registers in the wheel-parallel one
+    # vehicle_model.py:237-242): two fp64 fits, both pinned in registers in the lane kernel (one per axle), the lane's
+    # own wheel's in the wheel-parallel one; and with four different shape factors: the lane kernel reads the per-wheel
+    # table from LDS
     import importlib as _il
-    pw = _il.import_module("python-motionplanning_amd").VehicleParameters()
+    VPc = _il.import_module("python-motionplanning_amd").VehicleParameters
+    pw = VPc()
     pw.CRL = pw.CRR = 1.3
-    for name, lanes in (("", 1), ("_wheel_parallel", 4)):
-        vmp = type(vm)(2.906, np.deg2rad(30), DT, params=pw, device=vm.device, lanes_per_rollout=lanes)
-        vmp.rollout(s2d, c2d)
-        t = timed_launches(lambda: vmp.rollout(s2d, c2d), 5, torch)
-        ex[f"config2_4096x200_f64_rear_C_1.3{name}"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
+    p4 = VPc()
+    p4.CFR, p4.CRL, p4.CRR = 1.45, 1.3, 1.25
+    for tires, tag in ((pw, "rear_C_1.3"), (p4, "four_C")):
+        for name, lanes in (("", 1), ("_wheel_parallel", 4)):
+            vmp = type(vm)(2.906, np.deg2rad(30), DT, params=tires, device=vm.device, lanes_per_rollout=lanes)
+            vmp.rollout(s2d, c2d)
+            t = timed_launches(lambda: vmp.rollout(s2d, c2d), 5, torch)
+            ex[f"config2_4096x200_f64_{tag}{name}"] = {"steps_per_s": 4096 * HORIZON / t, "kernel_ms": t * 1e3}
     # the same launch with the steering table scaled by 8 (+-27 deg) and every fourth ego's wheels locked: tires
     # from zero slip to far past the friction peak (B s up to ~20).  The step has no data-dependent path -- the
     # fitted shape function covers every slip with one polynomial -- so this must cost what the headline costs.

@@ -112,6 +112,17 @@ __device__ __forceinline__ void stage_tire_fit(const DevParams<double> &)
 // then spills SGPRs into VGPR lanes and reads them back one `v_readlane_b32` at a time (105 per RK4 step before this,
 // 9 % of the instruction stream).  38 VGPRs is what the vector file has to spare: one set, not four.
 __device__ __forceinline__ void pin_tire_fit(DevParams<float> &) {}
+// One C per axle (front tires of one kind, rear tires of another -- the usual way a vehicle's wheels differ): columns
+// 0 and 2, both pinned (FITSRC 3).  76 VGPRs; the step still needs no accumulation register and no LDS read.
+__device__ __forceinline__ void pin_tire_fit_axles(DevParams<float> &) {}
+__device__ __forceinline__ void pin_tire_fit_axles(DevParams<double> &P)
+{
+#pragma unroll
+    for (int i = 0; i <= kTireFitDeg64; ++i) {
+        asm volatile("" : "+v"(P.W[i][0]));
+        asm volatile("" : "+v"(P.W[i][2]));
+    }
+}
 
 // W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(18 - i), the coefficients read from the
 // LDS table one degree (four doubles, two 16-byte reads) at a time.  Tried first: scalar loads straight from the
@@ -159,6 +170,14 @@ __device__ __forceinline__ void fit_horner4_lds(const double cc[4], double g[4])
             g[2] = ::fma(g[2], cc[2], w1.x); g[3] = ::fma(g[3], cc[3], w1.y);
         }
     }
+}
+
+// FS of the lane kernels that pin their fit: 1 = the one set the wheels share, 3 = one set per axle.
+template <int FS, typename T>
+__device__ __forceinline__ void pin_fit(DevParams<T> &P)
+{
+    if constexpr (FS == 3) pin_tire_fit_axles(P);
+    else pin_tire_fit(P);
 }
 
 // ---- scalar math, by type and by path ------------------------------------------------
@@ -462,13 +481,14 @@ __device__ __forceinline__ void planar_deriv(const DevParams<T> &P, const StepIn
         }
     } else {
         const T *W0 = fit_column0(P);
+        const T *WR = FITSRC == 3 && sizeof(T) == 8 ? W0 + 2 : W0;      // 3: the rear axle's own set (pin_tire_fit_axles)
         tire_force<T, true, SAFE, CS>(P.B[0], P.invB[0], P.C[0], W0, 4, P.rw, vLx, vFy, s[3], c.cd[0], c.sd[0],
                                       c.muFz[0], fx[0], fy[0], fxt[0], fyt[0], sl[0]);
         tire_force<T, true, SAFE, CS>(P.B[1], P.invB[1], P.C[1], W0, 4, P.rw, vRx, vFy, s[4], c.cd[1], c.sd[1],
                                       c.muFz[1], fx[1], fy[1], fxt[1], fyt[1], sl[1]);
-        tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], W0, 4, P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
+        tire_force<T, !K2, SAFE, CS>(P.B[2], P.invB[2], P.C[2], WR, 4, P.rw, vLx, vRy, s[5], c.cd[2], c.sd[2],
                                      c.muFz[2], fx[2], fy[2], fxt[2], fyt[2], sl[2]);
-        tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], W0, 4, P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
+        tire_force<T, !K2, SAFE, CS>(P.B[3], P.invB[3], P.C[3], WR, 4, P.rw, vRx, vRy, s[6], c.cd[3], c.sd[3],
                                      c.muFz[3], fx[3], fy[3], fxt[3], fyt[3], sl[3]);
     }
 

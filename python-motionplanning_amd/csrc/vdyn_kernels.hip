@@ -118,7 +118,7 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
 // (fit_horner4_lds); otherwise the handle's one set is pinned in VGPRs (pin_tire_fit).
 // COMP (fp32, CS): state0 / terminal are [22][n], rows 12..21 the compensation terms of the state sum
 // (VDYN_OPT_STATE_ROWS, StepEngine<float>::advance_state); trajectories keep 12 rows.
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true, bool PW = false, bool COMP = false>
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool TRAJ = true, int PW = 0, bool COMP = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                const T *__restrict__ ctrl, const int *__restrict__ path_id, int Pn, int chunk, T h,
@@ -126,10 +126,11 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                T *__restrict__ state_dot_out, T *__restrict__ outputs_out)
 {
     if (CS) {                           // only the fitted chain reads them
-        if (PW) stage_tire_fit(P);
+        if (PW == 1) stage_tire_fit(P);
+        else if (PW == 2) pin_tire_fit_axles(P);
         else pin_tire_fit(P);
     }
-    constexpr int FS = PW ? 2 : 1;
+    constexpr int FS = PW == 1 ? 2 : PW == 2 ? 3 : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *tab = reinterpret_cast<T *>(smem_raw);
 
@@ -247,13 +248,13 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
 // the wheelbase: the kinematic-bicycle steering angle of that curvature.
 // No control bytes come from memory at all: 12 B per ROLLOUT instead of 8 B per step, and
 // (sin delta, cos delta) are exact from the tangent -- cos = rsq(1 + tan^2) -- with no arctangent.
-template <typename T, bool CS, bool TRAJ>
+template <typename T, bool CS, bool TRAJ, int FS = 1>     // FS = 3: one fit per axle (pin_fit)
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2)))
 rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0, const T *__restrict__ spiral,
                       T wheelbase, T tan_max, T torque, T h, T *__restrict__ terminal, T *__restrict__ traj,
                       int traj_stride)
 {
-    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
+    if (CS) pin_fit<FS>(P);             // only the fitted chain reads them
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = gid < n;
     const int64_t r = active ? gid : n - 1;
@@ -281,7 +282,7 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
         const T cd = Math<T, false>::rsqrt(fma_t(q, q, T(1)));
         const T sd = q * cd;
         const T delta[4] = {q, q, T(0), T(0)};                     // PRE = 2: the tangent stands in for the angle
-        eng.template advance_state<true, CS, 2>(P, X, delta, tq, P.mu, h, sd, cd);
+        eng.template advance_state<true, CS, 2, FS>(P, X, delta, tq, P.mu, h, sd, cd);
     };
     int t = 0;
     if (!TRAJ) {                                                   // four steps per trip (see rollout_kernel)
@@ -570,13 +571,13 @@ mpc_prepare_kernel(DevParams<T> P, int C, int H, const T *__restrict__ cand, T *
     o[0] = d; o[1] = tq; o[2] = sd; o[3] = cd;
 }
 
-template <typename T, bool CS>
+template <typename T, bool CS, int FS = 1>
 __global__ void __launch_bounds__(mpc_block_max<T>(), mpc_waves_per_simd<T>())
 mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego,
                   const T *__restrict__ cand4, const T *__restrict__ goal, T h, T w_delta,
                   T *__restrict__ best_cost, int *__restrict__ best_idx, T *__restrict__ cost_all)
 {
-    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
+    if (CS) pin_fit<FS>(P);             // only the fitted chain reads them
     __shared__ T s_cost[16];
     __shared__ int s_idx[16];
     const int e = blockIdx.x;
@@ -602,15 +603,15 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
         for (; t + 1 < H; t += 2) {            // two steps per trip, control sets ping-pong (see rollout_kernel)
             c2.set_pre(P, cand4 + ((int64_t)(t + 1) * C + c) * 4);
             VDYN_FETCH_FENCE
-            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            eng.template advance_state<true, CS, 1, FS>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
             cc.set_pre(P, cand4 + ((int64_t)min(t + 2, H - 1) * C + c) * 4);
             VDYN_FETCH_FENCE
-            eng.template advance_state<true, CS, 1>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+            eng.template advance_state<true, CS, 1, FS>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             dsum += c2.delta[0] * c2.delta[0];
         }
         if (t < H) {
-            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            eng.template advance_state<true, CS, 1, FS>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
         }
         const T dx = X.get(8) - gx, dy = X.get(9) - gy;
@@ -648,13 +649,13 @@ mpc_argmin_kernel(DevParams<T> P, int E, int C, int H, const T *__restrict__ ego
 // the lowest index still wins ties and a NaN / inf cost never wins -- exactly the scan of the kernel above.
 //   grid = ceil(E / 64) * ceil(C / KC) waves, one wave per workgroup; KC is chosen by the launcher so that the grid is
 //   about two waves per SIMD (fp32; one for fp64) -- what the register budget of the packed step allows.
-template <typename T, bool CS>
+template <typename T, bool CS, int FS = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, sizeof(T) == 4 ? 2 : 1)))
 mpc_argmin_lanes_kernel(DevParams<T> P, int E, int C, int H, int KC, const T *__restrict__ ego,
                         const T *__restrict__ cand4, const T *__restrict__ goal, T h, T w_delta,
                         T *__restrict__ part_cost, int *__restrict__ part_idx, T *__restrict__ cost_all)
 {
-    if (CS) pin_tire_fit(P);            // only the fitted chain reads them
+    if (CS) pin_fit<FS>(P);             // only the fitted chain reads them
     const int ngroups = (E + 63) / 64;
     const int grp = (int)(blockIdx.x % (unsigned)ngroups), chunk = (int)(blockIdx.x / (unsigned)ngroups);
     const int e_raw = grp * 64 + (int)threadIdx.x;
@@ -683,15 +684,15 @@ mpc_argmin_lanes_kernel(DevParams<T> P, int E, int C, int H, int KC, const T *__
         for (; t + 1 < H; t += 2) {             // two steps per trip, control sets ping-pong
             c2.set_pre(P, tab + (int64_t)(t + 1) * ts);
             VDYN_FETCH_FENCE
-            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            eng.template advance_state<true, CS, 1, FS>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
             cc.set_pre(P, tab + (int64_t)min(t + 2, H - 1) * ts);
             VDYN_FETCH_FENCE
-            eng.template advance_state<true, CS, 1>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+            eng.template advance_state<true, CS, 1, FS>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             dsum += c2.delta[0] * c2.delta[0];
         }
         if (t < H) {
-            eng.template advance_state<true, CS, 1>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
+            eng.template advance_state<true, CS, 1, FS>(P, X, cc.delta, cc.tq, cc.mu, h, cc.sd0, cc.cd0);
             dsum += cc.delta[0] * cc.delta[0];
         }
         const T dx = X.get(8) - gx, dy = X.get(9) - gy;
@@ -864,7 +865,8 @@ size_t waypoint_aux_len(int P, int Wmax)
 //            (drive.py:145-151; names in plots.py:19-27): t, state x10, state_dot x10, delta,
 //            torque x4, outputs x18, crosstrack error.
 //   LOG: the launch writes the 16-row log (an instance of its own: see rollout_kernel's TRAJ)
-template <typename T, bool CS, bool WPLDS, bool DATALOG, bool LOG>
+//   FS:  how the fp64 fitted chain gets its coefficients without the DataLog (pin_fit): 1 one set, 3 one per axle
+template <typename T, bool CS, bool WPLDS, bool DATALOG, bool LOG, int FS = 1>
 __global__ void __launch_bounds__(kBlock)
 closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_every, int phase,
                    const T *__restrict__ state0, const T *__restrict__ cstate0, const T *__restrict__ wp,
@@ -877,7 +879,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
     constexpr bool kFitLds = DATALOG && sizeof(T) == 8;
     if (CS) {                           // only the fitted chain reads them
         if (kFitLds) stage_tire_fit(P);
-        else pin_tire_fit(P);
+        else pin_fit<FS>(P);
     }
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS image (ClosedLoopLds, vdyn_controls.hpp): x rows, y rows (padded to whole 8-waypoint sub-blocks, 16-byte
@@ -953,10 +955,10 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
             eng.steer_sincos(c.delta, sd0, cd0);
             int j = 0;
             for (; j + 1 < run; j += 2) {
-                eng.template advance_state<true, CS, 1>(P, X, delta, tq, P.mu, h, sd0, cd0);
-                eng.template advance_state<true, CS, 1>(P, X, delta, tq, P.mu, h, sd0, cd0);
+                eng.template advance_state<true, CS, 1, FS>(P, X, delta, tq, P.mu, h, sd0, cd0);
+                eng.template advance_state<true, CS, 1, FS>(P, X, delta, tq, P.mu, h, sd0, cd0);
             }
-            if (j < run) eng.template advance_state<true, CS, 1>(P, X, delta, tq, P.mu, h, sd0, cd0);
+            if (j < run) eng.template advance_state<true, CS, 1, FS>(P, X, delta, tq, P.mu, h, sd0, cd0);
             t += run;
             until_update -= run;
         }
@@ -978,13 +980,13 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
             T s[10], ax = X.get(10), ay = X.get(11);
 #pragma unroll
             for (int i = 0; i < 10; ++i) s[i] = X.get(i);
-            eng.template advance_diag<true, CS, kFitLds ? 2 : 1>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
+            eng.template advance_diag<true, CS, kFitLds ? 2 : FS>(P, s, ax, ay, delta, tq, P.mu, h, sd, o18);
 #pragma unroll
             for (int i = 0; i < 10; ++i) X.set(i, s[i]);
             X.set(10, ax);
             X.set(11, ay);
         } else {
-            eng.template advance_state<true, CS>(P, X, delta, tq, P.mu, h);
+            eng.template advance_state<true, CS, 0, FS>(P, X, delta, tq, P.mu, h);
         }
         if (DATALOG && active) {
             // written once, never read back by this kernel: streaming (non-temporal) stores
@@ -1576,7 +1578,19 @@ static bool lane_cs(const VdynParams &p, bool per_wheel = false)
     return tire_fit(p).ok64 && (per_wheel || same_shape_factor(p));
 }
 
-template <typename T, int K, int LAYOUT, bool DIAG, bool CS, bool PW = false, bool COMP = false>
+// How an fp64 lane kernel's FAST step gets its fit (fp32 kernels carry the four fits as packed pairs: always 1):
+//   0 the general chain; 1 one set pinned (the wheels share C); 3 one set per axle, both pinned (C_FL = C_FR,
+//   C_RL = C_RR: vehicle_model.py:237-242 sketches exactly that handle); 2 four sets, read from LDS -- the rollout
+//   kernel and the DataLog closed loop only: the kernels without that path send such a handle to the general chain.
+template <typename T>
+static int fit_mode(const VdynParams &p)
+{
+    if (!lane_cs<T>(p, true)) return 0;
+    if (sizeof(T) == 4 || same_shape_factor(p)) return 1;
+    return p.C[0] == p.C[1] && p.C[2] == p.C[3] ? 3 : 2;
+}
+
+template <typename T, int K, int LAYOUT, bool DIAG, bool CS, int PW = 0, bool COMP = false>
 static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> &a, hipStream_t st)
 {
     const DevParams<T> P = make_dev_params<T>(p, a.mu4);
@@ -1692,12 +1706,13 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     const bool diag = a.state_dot != nullptr || a.outputs != nullptr;
     const bool cs_quad = lane_cs<T>(p, true);                   // a lane of the wheel-parallel kernel holds its own wheel's fit
     const bool cs = cs_quad, pw = sizeof(T) == 8 && cs && !same_shape_factor(p);
+    const bool axles = pw && p.C[0] == p.C[1] && p.C[2] == p.C[3];     // one C per axle: two sets pinned, no LDS
     if (a.state_rows == 22) {
         // compensated state sum: fp32, lane per rollout, fitted chain (anything else: invalid value -> VDYN_ERR_ARG)
         if constexpr (sizeof(T) == 4) {
             if (cs && !diag) {
 #define VDYN_DISPATCH_C(KK, LL) \
-    if (a.k == KK && layout == LL) return launch_rollout_impl<T, KK, LL, false, true, false, true>(p, a, st);
+    if (a.k == KK && layout == LL) return launch_rollout_impl<T, KK, LL, false, true, 0, true>(p, a, st);
                 VDYN_DISPATCH_C(2, 0)
                 VDYN_DISPATCH_C(2, 1)
                 VDYN_DISPATCH_C(2, 2)
@@ -1727,7 +1742,8 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
     if (a.k == KK && layout == LL) {                                                   \
         if (diag) return launch_rollout_impl<T, KK, LL, true, false>(p, a, st);        \
         if constexpr (sizeof(T) == 8)                                                  \
-            if (pw) return launch_rollout_impl<T, KK, LL, false, true, true>(p, a, st); \
+            if (pw) return axles ? launch_rollout_impl<T, KK, LL, false, true, 2>(p, a, st) \
+                                 : launch_rollout_impl<T, KK, LL, false, true, 1>(p, a, st); \
         return cs ? launch_rollout_impl<T, KK, LL, false, true>(p, a, st)              \
                   : launch_rollout_impl<T, KK, LL, false, false>(p, a, st);            \
     }
@@ -1749,13 +1765,16 @@ hipError_t launch_rollout_spiral(const VdynParams &p, int64_t n, int H, const T 
     if (n <= 0) return hipSuccess;
     const DevParams<T> P = make_dev_params<T>(p, mu4);
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-#define VDYN_SPIRAL(CSV, TRV)                                                                              \
-    hipLaunchKernelGGL((rollout_spiral_kernel<T, CSV, TRV>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral, \
+#define VDYN_SPIRAL(CSV, TRV, FSV)                                                                         \
+    hipLaunchKernelGGL((rollout_spiral_kernel<T, CSV, TRV, FSV>), dim3(grid), dim3(kBlock), 0, st, P, n, H, state0, spiral, \
                        (T)wheelbase, (T)tan_max, (T)torque, (T)dt, terminal, traj, traj_stride > 0 ? traj_stride : 1)
-    if (lane_cs<T>(p)) {
-        if (traj != nullptr) VDYN_SPIRAL(true, true); else VDYN_SPIRAL(true, false);
+    const int fm = fit_mode<T>(p);
+    if (fm == 3) {
+        if constexpr (sizeof(T) == 8) { if (traj != nullptr) VDYN_SPIRAL(true, true, 3); else VDYN_SPIRAL(true, false, 3); }
+    } else if (fm == 1) {
+        if (traj != nullptr) VDYN_SPIRAL(true, true, 1); else VDYN_SPIRAL(true, false, 1);
     } else {
-        if (traj != nullptr) VDYN_SPIRAL(false, true); else VDYN_SPIRAL(false, false);
+        if (traj != nullptr) VDYN_SPIRAL(false, true, 1); else VDYN_SPIRAL(false, false, 1);
     }
 #undef VDYN_SPIRAL
     return hipGetLastError();
@@ -1848,10 +1867,15 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
     // below that a workgroup per ego wastes no lanes and needs no second kernel.  Both give the same bits
     // (tools/ubench/mpc_harness.hip); configs[4]: 0.306 against 0.311 ms per call.
     const bool lanes = E >= 512 && (int64_t)groups * C >= 1024;
+    const int fm = fit_mode<T>(p);
     if (!lanes) {
         int block = ((C + 63) / 64) * 64;
         block = std::max(64, std::min(block, mpc_block_max<T>()));
-        if (lane_cs<T>(p))
+        if (fm == 3) {
+            if constexpr (sizeof(T) == 8)
+                hipLaunchKernelGGL((mpc_argmin_kernel<T, true, 3>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
+                                   C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
+        } else if (fm == 1)
             hipLaunchKernelGGL((mpc_argmin_kernel<T, true>), dim3((unsigned)E), dim3((unsigned)block), 0, st, P, E,
                                C, H, ego, cand4, goal, (T)dt, (T)w_delta, best_cost, best_idx, cost_all);
         else
@@ -1863,7 +1887,11 @@ hipError_t launch_mpc_argmin(const VdynParams &p, int E, int C, int H, const T *
     T *part_cost = reinterpret_cast<T *>(static_cast<char *>(scratch) + tab);
     int *part_idx = reinterpret_cast<int *>(part_cost + (size_t)nchunks * E);
     const unsigned grid = (unsigned)((int64_t)groups * nchunks);
-    if (lane_cs<T>(p))
+    if (fm == 3) {
+        if constexpr (sizeof(T) == 8)
+            hipLaunchKernelGGL((mpc_argmin_lanes_kernel<T, true, 3>), dim3(grid), dim3(64), 0, st, P, E, C, H, KC, ego, cand4,
+                               goal, (T)dt, (T)w_delta, part_cost, part_idx, cost_all);
+    } else if (fm == 1)
         hipLaunchKernelGGL((mpc_argmin_lanes_kernel<T, true>), dim3(grid), dim3(64), 0, st, P, E, C, H, KC, ego, cand4,
                            goal, (T)dt, (T)w_delta, part_cost, part_idx, cost_all);
     else
@@ -1904,7 +1932,12 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
     // gfx950 has 160 KiB of LDS per CU; a workgroup may take all of it (one workgroup per
     // CU is also what 65536 vehicles give), beyond the 64 KiB default only after opting in
     const bool lds = wp_bytes <= kClosedLoopLdsBudget;
-    const bool cs = lane_cs<T>(p);
+    // the fitted chain: with the DataLog the fp64 kernel reads the per-wheel table from LDS (any handle whose fits
+    // passed their check); without it the fits are pinned -- one set, or one per axle (fit_mode)
+    const int fm = fit_mode<T>(p);
+    const bool dl = a.datalog != nullptr;
+    const bool ax = sizeof(T) == 8 && !dl && fm == 3;
+    const bool cs = fm == 1 || (sizeof(T) == 8 && dl && fm != 0);
     // tables in LDS: the kernel builds its whole image itself; otherwise the transposed tables in `aux`
     if (a.aux != nullptr && !lds) {
         const int64_t tiles = (int64_t)((a.P + kAuxTP - 1) / kAuxTP) * ((a.Wmax + kAuxTJ - 1) / kAuxTJ);
@@ -1918,24 +1951,29 @@ hipError_t launch_closed_loop(const VdynParams &p, const VdynCtrlGains &g, const
             if (e_ != hipSuccess) return e_;
         }
     }
-#define VDYN_CL3(CSV, LDSV, DLV, LGV)                                                                 \
+#define VDYN_CL3(CSV, LDSV, DLV, LGV, FSV)                                                            \
     {                                                                                                 \
         if (LDSV && wp_bytes > 64 * 1024) {                                                           \
             hipError_t e_ = hipFuncSetAttribute(                                                      \
-                reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV, DLV, LGV>),          \
+                reinterpret_cast<const void *>(&closed_loop_kernel<T, CSV, LDSV, DLV, LGV, FSV>),     \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)wp_bytes);                           \
             if (e_ != hipSuccess) return e_;                                                          \
         }                                                                                             \
-        hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV, LGV>), dim3(grid), dim3(kBlock),    \
+        hipLaunchKernelGGL((closed_loop_kernel<T, CSV, LDSV, DLV, LGV, FSV>), dim3(grid), dim3(kBlock), \
                            LDSV ? wp_bytes : 0, st, P, G, a.n, a.H, a.ctrl_every, a.phase, a.state0,  \
                            a.cstate0, a.wp, a.Wmax, a.wcount, a.path_id, a.P, (T)a.dt, a.terminal,    \
                            a.cstate, a.log, a.datalog, (const T *)a.aux);                             \
     }
-#define VDYN_CL2(CSV, LDSV, DLV)                                                                      \
-    if (a.log != nullptr) VDYN_CL3(CSV, LDSV, DLV, true) else VDYN_CL3(CSV, LDSV, DLV, false)
+#define VDYN_CL2(CSV, LDSV, DLV, FSV)                                                                 \
+    if (a.log != nullptr) VDYN_CL3(CSV, LDSV, DLV, true, FSV) else VDYN_CL3(CSV, LDSV, DLV, false, FSV)
 #define VDYN_CL(CSV, LDSV)                                                                            \
-    if (a.datalog != nullptr) { VDYN_CL2(CSV, LDSV, true) } else { VDYN_CL2(CSV, LDSV, false) }
-    if (cs && lds) { VDYN_CL(true, true) }
+    if (dl) { VDYN_CL2(CSV, LDSV, true, 1) } else { VDYN_CL2(CSV, LDSV, false, 1) }
+    if (ax) {
+        if constexpr (sizeof(T) == 8) {
+            if (lds) { VDYN_CL2(true, true, false, 3) } else { VDYN_CL2(true, false, false, 3) }
+        }
+    }
+    else if (cs && lds) { VDYN_CL(true, true) }
     else if (cs) { VDYN_CL(true, false) }
     else if (lds) { VDYN_CL(false, true) }
     else { VDYN_CL(false, false) }

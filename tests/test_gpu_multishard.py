@@ -119,6 +119,7 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
     n_total = 2 * per_gpu if mode == "weak" else per_gpu
     assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["rollouts_total"] == n_total and out["scaling"] == mode
     assert out["shards"] == [list(workloads.shard_egos(n_total, 2, r)) for r in range(2)]
+    assert "bitwise" in out["exchange"].pop("verified_how")
     assert out["exchange"] == {"kind": "peer_copies" if exchange in ("p2p", "auto") else "all_gather_into_tensor",
                                "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4, "verified": True,
                                "requested": exchange, "fallback_reason": None}
@@ -155,6 +156,7 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["world_seen"] == 1 and out["rollouts_total"] == 65536
     assert out["dist_backend"] == "nccl"
+    assert "bitwise" in out["exchange"].pop("verified_how")
     assert out["exchange"] == {"kind": "all_gather_into_tensor" if exchange == "rccl" else "peer_copies",
                                "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True,
                                "requested": exchange, "fallback_reason": None}
