@@ -8,7 +8,7 @@
 set -eo pipefail
 TAG=${1:-r02}
 shift || true
-CASES=${*:-"config2_f64_lane config2_f64_wheel config5_mpc closed_loop closed_loop_datalog trajectory_dump per_rollout_controls spiral_lattice"}
+CASES=${*:-"config2_f64_lane config2_f64_wheel config2_f64_axles config2_f64_four_c config5_mpc closed_loop closed_loop_datalog trajectory_dump per_rollout_controls spiral_lattice"}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/profk_$TAG
 mkdir -p "$OUT/summary"

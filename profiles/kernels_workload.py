@@ -22,7 +22,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-CASES = ("headline", "per_rollout_controls", "config2_f64_lane", "config2_f64_wheel", "config5_mpc",
+CASES = ("headline", "per_rollout_controls", "config2_f64_lane", "config2_f64_wheel", "config2_f64_axles",
+         "config2_f64_four_c", "config5_mpc",
          "closed_loop", "closed_loop_datalog", "trajectory_dump", "spiral_lattice")
 
 
@@ -48,22 +49,32 @@ def build(case, pkg, torch, dev):
         return (lambda: vm.rollout(s0d, ctrl)), dict(
             kernel="rollout_kernel<float, 2, 0, false, true", steps_per_lane=H, vehicle_steps=n * H,
             algo_bytes=96 * n + 8 * n * H, dynamic_lds_bytes=0)
-    if case in ("config2_f64_lane", "config2_f64_wheel"):
+    if case in ("config2_f64_lane", "config2_f64_wheel", "config2_f64_axles", "config2_f64_four_c"):
         H = 200
         s2, c2 = W.config2(64, H)
         s2d, c2d = torch.from_numpy(s2).to(dev), torch.from_numpy(c2).to(dev)
         if case.endswith("wheel"):
             vm = VM(2.906, np.deg2rad(30), 1e-3, device=0, lanes_per_rollout=4)
+        if case.endswith(("axles", "four_c")):
+            # tires that differ by axle (two fits pinned in registers, rollout_kernel<..., PW = 2>) or by wheel
+            # (the per-wheel table in LDS, PW = 1): csrc/vdyn_kernels.hip fit_mode
+            tires = pkg.VehicleParameters()
+            tires.CRL = tires.CRR = 1.3
+            if case.endswith("four_c"):
+                tires.CFR, tires.CRR = 1.45, 1.25
+            vm = VM(2.906, np.deg2rad(30), 1e-3, device=0, params=tires)
         return (lambda: vm.rollout(s2d, c2d)), dict(
             kernel=("rollout_quad_kernel<double, 2, 0, true, false" if case.endswith("wheel")
-                    else "rollout_kernel<double, 2, 0, false, true"),
+                    else "rollout_kernel<double, 2, 0, false, true, false, 2" if case.endswith("axles")
+                    else "rollout_kernel<double, 2, 0, false, true, false, 1" if case.endswith("four_c")
+                    else "rollout_kernel<double, 2, 0, false, true, false, 0"),
             steps_per_lane=H, vehicle_steps=4096 * H, algo_bytes=192 * 4096 + 16 * 4096 * H, dynamic_lds_bytes=0)
     if case == "config5_mpc":
         E, C, H = 1024, 512, 50
         ego, cand, goal = (torch.from_numpy(a).to(dev) for a in W.config5(E, C, H))
         return (lambda: vm.mpc_argmin(ego, cand, goal, dt=2e-3, w_delta=W.MPC_W_DELTA)), dict(
             # egos on the lanes: a wave = 64 egos x a chunk of KC = 4 candidates (launch_mpc_argmin), 4 x 50 steps per lane
-            kernel="mpc_argmin_lanes_kernel<float, true>", steps_per_lane=4 * H, vehicle_steps=E * C * H,
+            kernel="mpc_argmin_lanes_kernel<float, true", steps_per_lane=4 * H, vehicle_steps=E * C * H,
             algo_bytes=(12 + 2 + 2) * 4 * E + cand.numel() * 4, dynamic_lds_bytes=0)
     if case in ("closed_loop", "closed_loop_datalog"):
         n = 65536
