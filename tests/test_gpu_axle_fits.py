@@ -178,3 +178,12 @@ def test_closed_loop_axle_fits_log_datalog_and_global_tables(pkg, gpu_vm, oracle
     # the reference tires steer differently: the rear set was really used
     t0, _ = gpu_vm(dt).closed_loop(s0, c0, wp, H, wcount=wc, path_id=pid, gains=gg)
     assert np.abs(t0 - term).max() > 1e-6
+    # four different C: with the DataLog the fitted chain from the LDS table, without it the general chain -- both
+    # against the oracle, and against each other to rounding
+    v4 = _four_c_vehicle(pkg)
+    o4, _, _ = oracle.closed_loop(oracle.params_from(v4), cp, s0, c0, wp, wc, pid, dt, H, log=True, nthreads=8)
+    vm4 = gpu_vm(dt, params=v4)
+    t5 = vm4.closed_loop(s0, c0, wp, H, wcount=wc, path_id=pid, gains=gg, datalog=True)[0]
+    t6 = vm4.closed_loop(s0, c0, wp, H, wcount=wc, path_id=pid, gains=gg)[0]
+    assert parity(t5, o4, F64_TOL, "closed loop + DataLog, four C") <= 1e-9
+    assert parity(t6, o4, F64_TOL, "closed loop, four C, general chain") <= 1e-9
