@@ -114,6 +114,26 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
 // issued a whole step earlier.  A/B on one box, two runs each: headline 0.1540 -> 0.1534 ms, per-rollout controls
 // (global loads) 0.1683 -> 0.1633 ms, configs[1] fp64 0.5235 -> 0.4927 ms; MPC and the closed loop unchanged.
 #define VDYN_FETCH_FENCE __builtin_amdgcn_sched_barrier(0);
+
+// Where the next trajectory row goes.  Row j of traj [H / stride][12][n] is the state after step (j + 1) * stride of
+// the launch: a wave-uniform countdown and a running pointer -- `(t + 1) % stride == 0` and `(t + 1) / stride` are a
+// scalar division each (no such instruction: ~30 issue slots per step for a lone wave, a tenth of the step).
+template <typename T>
+struct TrajCursor {
+    T *row;
+    int64_t pitch;      // elements from one row to the next: 12 n
+    int left, stride;
+    __device__ __forceinline__ TrajCursor(T *traj, int64_t r, int64_t n, int stride_)
+        : row(traj != nullptr ? traj + r : nullptr), pitch(12 * n), left(stride_), stride(stride_) {}
+    // after every step; true: this step's state is a trajectory row -- store it at row, then call next()
+    __device__ __forceinline__ bool due()
+    {
+        if (--left != 0) return false;
+        left = stride;
+        return row != nullptr;
+    }
+    __device__ __forceinline__ void next() { row += pitch; }
+};
 // PW (fp64, CS): the four wheels differ in C -- the per-wheel fit table goes to LDS and the step reads it from there
 // (fit_horner4_lds); otherwise the handle's one set is pinned in VGPRs (pin_tire_fit).
 // COMP (fp32, CS): state0 / terminal are [22][n], rows 12..21 the compensation terms of the state sum
@@ -152,6 +172,16 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     constexpr int PRE = rollout_table_pre<K, LAYOUT, DIAG>() ? 1 : 0;
     if (!DIAG) eng.template init<true, CS>(P);
 
+    TrajCursor<T> tcur(TRAJ ? traj : nullptr, r, n, traj_stride);
+    auto dump = [&]() __attribute__((always_inline)) {
+        if (tcur.due()) {
+            if (active) {                                           // written once: streaming stores
+#pragma unroll
+                for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), tcur.row + (int64_t)i * n);
+            }
+            tcur.next();
+        }
+    };
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
@@ -197,7 +227,6 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
             }
         }
         for (; tc < tc_n; ++tc) {
-            const int t = t0 + tc;
             Ctrl<T, K> cn;
             fetch(cn, min(tc + 1, tc_n - 1));
 
@@ -214,12 +243,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
             }
             c = cn;
-
-            if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
-                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;   // written once: streaming stores
-#pragma unroll
-                for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), row + (int64_t)i * n);
-            }
+            if (TRAJ) dump();
         }
     }
 
@@ -293,12 +317,15 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
             one_step(t + 3);
         }
     }
+    TrajCursor<T> tcur(TRAJ ? traj : nullptr, r, n, traj_stride);
     for (; t < H; ++t) {
         one_step(t);
-        if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
-            T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
+        if (TRAJ && tcur.due()) {
+            if (active) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), row + (int64_t)i * n);
+                for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), tcur.row + (int64_t)i * n);
+            }
+            tcur.next();
         }
     }
     if (active) {
@@ -374,6 +401,7 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
     StepEngine<T> eng;
     eng.template init<false, CS>(P);   // per-lane constants
 
+    TrajCursor<T> tcur(traj, r, n, traj_stride);
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
@@ -390,17 +418,19 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
         Ctrl<T, K> c;
         fetch(c, 0);
         for (int tc = 0; tc < tc_n; ++tc) {
-            const int t = t0 + tc;
             Ctrl<T, K> cn;
             fetch(cn, min(tc + 1, tc_n - 1));          // behind this step (see rollout_kernel)
             eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
             c = cn;
-            if (traj != nullptr && (t + 1) % traj_stride == 0 && active) {
-                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;   // written once: streaming stores
+            if (tcur.due()) {
+                if (active) {                          // written once: streaming stores
+                    T *row = tcur.row;
 #pragma unroll
-                for (int i = 0; i < 10; ++i) __builtin_nontemporal_store(s[i], row + (int64_t)i * n);
-                __builtin_nontemporal_store(ax, row + 10 * n);
-                __builtin_nontemporal_store(ay, row + 11 * n);
+                    for (int i = 0; i < 10; ++i) __builtin_nontemporal_store(s[i], row + (int64_t)i * n);
+                    __builtin_nontemporal_store(ax, row + 10 * n);
+                    __builtin_nontemporal_store(ay, row + 11 * n);
+                }
+                tcur.next();
             }
         }
     }
@@ -447,6 +477,7 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
     int pid = 0;
     if (LAYOUT != 0) pid = min(max(path_id[r], 0), Pn - 1);
 
+    TrajCursor<T> tcur(TRAJ ? traj : nullptr, r, n, traj_stride);
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
@@ -477,19 +508,21 @@ rollout_quad_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ stat
         };
         QC cur = fetch(0);
         for (int tc = 0; tc < tc_n; ++tc) {
-            const int t = t0 + tc;
             const QC nxt = fetch(min(tc + 1, tc_n - 1));
             VDYN_FETCH_FENCE
             qe.template advance<CS>(P, L, s, ax, ay, cur.delta, cur.tq, cur.mu, h);
             cur = nxt;
 
-            if (TRAJ && traj != nullptr && (t + 1) % traj_stride == 0 && active) {
-                T *row = traj + (int64_t)((t + 1) / traj_stride - 1) * 12 * n + r;
-                row[(int64_t)(3 + q) * n] = s.w;
-                if (q == 0) {
-                    row[0] = s.U; row[n] = s.V; row[2 * n] = s.wz; row[7 * n] = s.yaw;
-                    row[8 * n] = s.x; row[9 * n] = s.y; row[10 * n] = ax; row[11 * n] = ay;
+            if (TRAJ && tcur.due()) {
+                if (active) {
+                    T *row = tcur.row;
+                    row[(int64_t)(3 + q) * n] = s.w;
+                    if (q == 0) {
+                        row[0] = s.U; row[n] = s.V; row[2 * n] = s.wz; row[7 * n] = s.yaw;
+                        row[8 * n] = s.x; row[9 * n] = s.y; row[10 * n] = ax; row[11 * n] = ay;
+                    }
                 }
+                tcur.next();
             }
         }
     }

@@ -13,7 +13,8 @@ FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fno-fast-math", "--cuda-device
 
 
 @pytest.mark.parametrize("src,defs", [("mpc_harness.hip", []), ("f64_harness.hip", []), ("cl_harness.hip", []),
-                                      ("cl_harness.hip", ["-DVDYN_STAMPS"])])
+                                      ("cl_harness.hip", ["-DVDYN_STAMPS"]), ("store_rate.hip", []),
+                                      ("rcp64_probe.hip", [])])
 def test_ubench_harness_compiles(src, defs):
     import importlib
     hipcc = importlib.import_module("python-motionplanning_amd._build").hipcc_path()
