@@ -1151,15 +1151,23 @@ def test_fitted_tire_chain_across_slip_regimes(gpu_vm, pkg, oracle, workloads):
 
 
 def test_rollout_fuzz_shapes_layouts_kernels(pkg, oracle, workloads):
-    """48 seeded combinations of batch size (1..3000, ragged against the 64-lane wave and the
+    """72 seeded combinations of batch size (1..3000, ragged against the 64-lane wave and the
     256-thread workgroup), horizon (0..40), control layout (per-rollout / shared with 1..40 paths),
     k (2 / 12), precision, kernel (lane / wheel-parallel) and tire set (the reference's; one random B, C for all
-    wheels; random B, C per wheel -- every one fitted on the host before the launch), each against the oracle."""
+    wheels; random B, C per wheel; random B, C per AXLE (fp64: two pinned fits) -- every one fitted on the host before
+    the launch), each against the oracle.  Cases 48..71 were added with the per-axle form and draw from generators of
+    their own, so that the first 48 are the cases they always were."""
     rng = np.random.default_rng(2024)
     trng = np.random.default_rng(77)
-    for case in range(48):
+    rng2, trng2 = np.random.default_rng(4202), np.random.default_rng(78)
+    for case in range(72):
         veh = pkg.VehicleParameters()
-        if case % 3 == 1:
+        if case >= 48:
+            rng, trng = rng2, trng2
+            bf, cf, br, cr = trng.uniform(12, 28), trng.uniform(0.8, 2.0), trng.uniform(12, 28), trng.uniform(0.8, 2.0)
+            veh.BFL = veh.BFR = float(bf); veh.CFL = veh.CFR = float(cf)
+            veh.BRL = veh.BRR = float(br); veh.CRL = veh.CRR = float(cr)
+        elif case % 3 == 1:
             veh = pkg.VehicleParameters(BFL=float(trng.uniform(12, 28)), CFL=float(trng.uniform(0.8, 2.0)))
         elif case % 3 == 2:
             for w in ("FL", "FR", "RL", "RR"):
@@ -1171,7 +1179,7 @@ def test_rollout_fuzz_shapes_layouts_kernels(pkg, oracle, workloads):
         k = int(rng.choice([2, 12]))
         shared = bool(rng.integers(0, 2))
         P = int(rng.integers(1, 41))
-        dtype = np.float64 if case % 3 else np.float32
+        dtype = np.float64 if case % 3 or case >= 48 else np.float32
         lanes = 4 if case % 4 == 1 else 1
         dt = 1e-3
         s0, _ = workloads.config2(int(np.ceil(np.sqrt(n))), 1)
