@@ -66,6 +66,9 @@ template <typename T> struct Lib;
 // where the argument allows and the library only beyond (|yaw| > 2^16).  fp64 stays on the library.
 template <> struct Lib<float> {
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    // v_sqrt_f32 (1 ulp, no denormal fix-up): the lookahead's first term and the crosstrack error, both compared
+    // against metres; the IEEE form above stays where rounded roots decide an index (nearest_in_subblocks_exact)
+    static __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float atan(float x) { return fm::atan_rcp(x, fm::rcp(x)); }
     static __device__ __forceinline__ float atan2(float y, float x)
     {
@@ -110,6 +113,7 @@ template <> struct Lib<float> {
 };
 template <> struct Lib<double> {
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double atan(double x) { return ::atan(x); }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
@@ -919,7 +923,7 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
     PhaseClock pc;
     VDYN_PHASE_START(pc);
     // :68-76 walk forward until the accumulated arc length reaches the lookahead distance
-    T total = L::sqrt(best_d2);
+    T total = L::sqrt_fast(best_d2);
     int ce = best_i;
     T px, py;
     wp.get(best_i, px, py);
@@ -1016,10 +1020,15 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
     L::sincos(yaw, &sy, &cy);
     const T v0 = px - x - G.lookahead * cy;
     const T v1 = py - y - G.lookahead * sy;
-    T cte = L::sqrt(v0 * v0 + v1 * v1);
+    T cte = L::sqrt_fast(v0 * v0 + v1 * v1);
     if (cte < G.deadband) cte = T(0);
-    // :101-104
-    const T che = wrap_pi<T>(L::atan2(v1, v0) - yaw);
+    // :101-104: only the SIGN of the wrapped angle between the vector to the target and the heading is used.  fp64
+    // forms the angle as the reference does; fp32 takes the sign of sin(angle) |v| = v1 cos(yaw) - v0 sin(yaw), which
+    // is the same sign on (-pi, pi) without an arctangent and a wrap (~40 instructions of an update's ~1200), and at
+    // least as well conditioned as the difference of two rounded angles
+    T che;
+    if constexpr (sizeof(T) == 4) che = v1 * cy - v0 * sy;
+    else che = wrap_pi<T>(L::atan2(v1, v0) - yaw);
     const T sign = che > T(0) ? T(1) : (che < T(0) ? T(-1) : che);  // np.sign: 0 and nan pass through
     // :109-120 trajectory heading; wraps from the last waypoint to the first
     T ax_, ay_, bx_, by_;
@@ -1028,7 +1037,14 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
         wp.get(inner ? ce : wp.W - 1, ax_, ay_);
         wp.get(inner ? ce + 1 : 0, bx_, by_);
     }
-    const T he = wrap_pi<T>(L::atan2(by_ - ay_, bx_ - ax_) - yaw);         // :122-123
+    T he;                                                                  // :122-123
+    if constexpr (sizeof(T) == 4) {
+        // the segment direction turned into the vehicle's frame first: atan2 of (cross, dot) IS the wrapped difference
+        const T dx_ = bx_ - ax_, dy_ = by_ - ay_;
+        he = L::atan2(dy_ * cy - dx_ * sy, dx_ * cy + dy_ * sy);
+    } else {
+        he = wrap_pi<T>(L::atan2(by_ - ay_, bx_ - ax_) - yaw);
+    }
     T steer = he + L::atan(L::div(G.k * sign * cte, v + G.k_soft));        // :124-126
     steer = steer < -G.max_steer ? -G.max_steer : steer;                   // :128 np.clip
     steer = steer > G.max_steer ? G.max_steer : steer;
@@ -1047,7 +1063,7 @@ __device__ __forceinline__ void long_control(const CtrlGains<T> &G, T desired, T
     total = total + vel_error * dt;
     const T p = G.kp * vel_error;
     const T i = G.ki * total;
-    const T d = G.kd * (current - prev) / dt;
+    const T d = Lib<T>::div(G.kd * (current - prev), dt);       // fp64: the division; fp32: times v_rcp_f32(dt)
     T tau = p + i + d;
     if (current <= T(0.01)) tau = abs_t(tau);
     tau_out = tau;
