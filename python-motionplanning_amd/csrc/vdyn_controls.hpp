@@ -951,14 +951,19 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
             T cw[kWin];
 #pragma unroll
             for (int k = 0; k < kWin; ++k) cw[k] = wp.seg_at(min(w0 + k, last));
-            // window entries below the target raise lo, entries at or above it lower hi (cum is non-decreasing)
+            // Window entries below the target raise lo, entries at or above it lower hi.  cum is a running sum of
+            // non-negative lengths: non-decreasing, and a NaN (a non-finite waypoint) poisons everything after it -- so
+            // along the window the entries are a run of "below", then a run of "at or above", then NaNs, and two
+            // COUNTS say where the runs meet (two instructions per entry and count, where a compare-and-select per
+            // entry and bound took nineteen: a sixth of the update's instructions went into this loop).
+            int n_below = 0, n_above = 0;
 #pragma unroll
             for (int k = 0; k < kWin; ++k) {
-                const int i = min(w0 + k, last);
-                const bool below = cw[k] < target;
-                lo = below && i > lo ? i : lo;
-                hi = !below && i < hi && cw[k] == cw[k] ? i : hi;
+                n_below += cw[k] < target ? 1 : 0;
+                n_above += cw[k] >= target ? 1 : 0;          // false for NaN: never lowers hi
             }
+            lo = n_below > 0 ? max(lo, min(w0 + n_below - 1, last)) : lo;
+            hi = n_above > 0 ? min(hi, min(w0 + n_below, last)) : hi;
             while (__any(hi - lo > 1)) {                          // normally zero trips: the window bracketed the crossing
                 const int mid = (lo + hi) >> 1;
                 const T cm = wp.seg_at(mid);
