@@ -1052,6 +1052,15 @@ def test_heterogeneous_fleet_rollout(gpu_vm, pkg, oracle, workloads):
     assert np.array_equal(vm.rollout_fleet(s0, ctrl, classes, vid), got)            # per-rollout controls layout
     one = vm.rollout_fleet(s0, tab, [classes[0]], np.zeros(n, np.int32), path_id=pid)
     assert np.array_equal(one, gpu_vm(dt, params=classes[0]).rollout(s0, tab, path_id=pid))
+    # trajectory rows (a stride that does not divide the horizon: 11 rows of 7 steps, 3 steps left over): row j is the
+    # terminal state of a launch of 7 (j + 1) steps, bit for bit, in both layouts and precisions
+    for a, tabs in ((s0, tab), (s0.astype(np.float32), tab.astype(np.float32))):
+        t2, traj = vm.rollout_fleet(a, tabs, classes, vid, path_id=pid, traj_stride=7)
+        assert traj.shape == (H // 7, 12, n) and np.array_equal(t2, vm.rollout_fleet(a, tabs, classes, vid, path_id=pid))
+        for j in (0, 4, H // 7 - 1):
+            assert np.array_equal(traj[j], vm.rollout_fleet(a, tabs[:, :7 * (j + 1)].copy(), classes, vid, path_id=pid)), j
+    _, traj_c = vm.rollout_fleet(s0, ctrl, classes, vid, traj_stride=7)
+    assert np.array_equal(traj_c, vm.rollout_fleet(s0, tab, classes, vid, path_id=pid, traj_stride=7)[1])
     with pytest.raises(ValueError):
         vm.rollout_fleet(s0, tab, classes, vid + 3, path_id=pid)
 
