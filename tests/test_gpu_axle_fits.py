@@ -187,3 +187,35 @@ def test_closed_loop_axle_fits_log_datalog_and_global_tables(pkg, gpu_vm, oracle
     t6 = vm4.closed_loop(s0, c0, wp, H, wcount=wc, path_id=pid, gains=gg)[0]
     assert parity(t5, o4, F64_TOL, "closed loop + DataLog, four C") <= 1e-9
     assert parity(t6, o4, F64_TOL, "closed loop, four C, general chain") <= 1e-9
+
+
+@pytest.mark.parametrize("k", [2, 12])
+def test_axle_fits_chunked_and_too_wide_shared_tables(pkg, gpu_vm, oracle, k):
+    """The per-axle instances of the two remaining control layouts: a shared table longer than one LDS chunk (several
+    stagings per launch) and one too wide for LDS at all (P = 1700 paths: read through L2, layout 2 -- for k = 12 the one
+    instance of the round's census with a few bytes of scratch), with trajectory rows, against the per-rollout
+    expansion bit for bit and the oracle."""
+    rng = np.random.default_rng(19)
+    veh = _axle_vehicle(pkg)
+    vm = gpu_vm(5e-4, params=veh)
+    p = oracle.params_from(veh)
+    for P, H, n in ((7, 900 if k == 2 else 400, 200), (1700, 6, 900)):
+        tab = np.empty((P, H, k))
+        if k == 2:
+            tab[:, :, 0] = rng.uniform(-0.2, 0.2, (P, H))
+            tab[:, :, 1] = rng.uniform(-100, 300, (P, H))
+        else:
+            tab[:, :, 0:2] = rng.uniform(-0.2, 0.2, (P, H, 1))
+            tab[:, :, 2:4] = rng.uniform(-0.02, 0.02, (P, H, 2))
+            tab[:, :, 4:8] = rng.uniform(-100, 300, (P, H, 4))
+            tab[:, :, 8:12] = rng.uniform(0.5, 1.0, (P, H, 4))
+        pid = rng.integers(0, P, n).astype(np.int32)
+        s0 = np.zeros((12, n))
+        s0[0] = rng.uniform(10, 30, n)
+        s0[3:7] = s0[0] / 0.308309813617345
+        a, traj = vm.rollout(s0, tab, path_id=pid, traj_stride=3)
+        b = vm.rollout(s0, np.ascontiguousarray(np.transpose(tab[pid], (1, 2, 0))))
+        assert np.array_equal(a, b) and np.array_equal(vm.rollout(s0, tab, path_id=pid), a)
+        want, wtraj = oracle.rollout(p, s0, tab, 5e-4, path_id=pid, traj_stride=3, nthreads=4)
+        assert parity(a, want, F64_TOL, f"axle fits, P={P} H={H} k={k}") <= 1e-8
+        assert parity(traj, wtraj, F64_TOL, "its trajectory") <= 1e-8
