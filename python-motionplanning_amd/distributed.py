@@ -154,15 +154,25 @@ class PeerExchange:
         if x is None:
             return None, why
         if self_test:
+            # in two agreed stages, so that a rank whose pushes fail never leaves the others inside result()'s barriers:
+            # (1) push and wait for the own copies -- no collective inside; (2) the collective read-back and the check
             ok = True
             try:
                 src = like.new_full((x.rows, sh.n_local), float(sh.rank + 1))
                 x.start(src)
+                x.wait()
+            except Exception as e:                      # noqa: BLE001 -- any failure means "do not use"
+                ok, why = False, f"self test: pushing to the peers raised {e!r}"
+                x._pending = None
+            if not x._agree(ok):
+                x.close()
+                return None, why or "self test: a rank could not push its block to its peers"
+            try:
                 got = x.result()
                 for r, (lo, hi) in enumerate(sh.bounds):
                     ok = ok and bool((got[:, lo:hi] == float(r + 1)).all())
-            except Exception as e:                      # noqa: BLE001 -- any failure means "do not use"
-                ok, why = False, f"self test raised {e!r}"
+            except Exception as e:                      # noqa: BLE001
+                ok, why = False, f"self test: reading the slots back raised {e!r}"
             if not x._agree(ok):
                 x.close()
                 return None, why or "self test: a rank did not receive every rank's block"
