@@ -70,9 +70,9 @@ def is_stale():
             return True
     except OSError:
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    # the hash covers every source, header and flag: a file that is merely NEWER than the library (a checkout, a copy
+    # onto the GPU box) with the same content is not a reason to compile for four minutes
+    return False
 
 
 def build(force=False, verbose=False, extra_flags=()):
