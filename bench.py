@@ -77,6 +77,12 @@ def parse(argv=None):
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 code path (RCCL all-gather of terminal states, overlapped with the "
                          "next launch) even with one rank: rehearsal of the multi-GPU path on a 1-GPU box")
+    ap.add_argument("--no-sections", action="store_true",
+                    help="N>1 (or --force-collective): skip what follows the timed region -- `exchange_ab` (RCCL vs peer "
+                         "copies, K/2 steps each) and `strong` (the fixed-65536 split, lane and wheel-parallel kernels)")
+    ap.add_argument("--sections-timeout-s", type=float, default=240.0,
+                    help="watchdog over those sections: past it every rank ends and rank 0 prints the headline line as "
+                         "it stands, with `sections_timed_out`")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each all-gather before the next launch (A/B of the overlap)")
     return ap.parse_args(argv)
@@ -258,11 +264,19 @@ class HipCompute:
             raise SystemExit(f"rank with LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible: "
                              "--gpus N needs N GPUs on this node")
         torch.cuda.set_device(local_rank)
-        self.torch = torch
+        self.torch, self.pkg, self.dt = torch, pkg, dt
         self.device = torch.device("cuda", local_rank)
         self.vm = pkg.VehicleModel(2.906, np.deg2rad(30), dt, device=local_rank, lanes_per_rollout=lanes_per_rollout)
         self.backend = dist_backend
         self.hip = True
+
+    def with_lanes(self, lanes_per_rollout):
+        """The same rank's compute with another lane mapping (4 = wheel-parallel): a second handle on the same device."""
+        import copy
+        o = copy.copy(self)
+        o.vm = self.pkg.VehicleModel(2.906, np.deg2rad(30), self.dt, device=self.device.index,
+                                     lanes_per_rollout=lanes_per_rollout)
+        return o
 
     def rollout(self, s0, tab, pid):
         return self.vm.rollout(s0, tab, path_id=pid)
@@ -287,6 +301,9 @@ def run(args, compute_factory=None):
     """One rank of the bench.  ``compute_factory(pkg, local_rank, lanes_per_rollout, dt)`` builds
     the per-rank compute (default: HipCompute); tests/test_bench_multirank.py passes a CPU
     stand-in to rehearse THIS function's sharding, exchange, timing and JSON with gloo ranks."""
+    import gc
+    import threading
+    from types import SimpleNamespace
     import torch
     import torch.distributed as dist
 
@@ -316,106 +333,126 @@ def run(args, compute_factory=None):
         kw = {"device_id": dev} if cp.backend == "nccl" else {}
         dist.init_process_group(cp.backend, rank=rank, world_size=world, **kw)
 
-    # workload: whole egos per rank (workloads.shard_egos through ShardedRollout), resident on the device
-    n_total = total_rollouts(world, per_gpu, args.strong)
-    sh = D.ShardedRollout(n_total)
-    assert sh.world == world and sh.rank == rank
-    lo, hi, n_local = sh.lo, sh.hi, sh.n_local
-    s0_all, tab, pid_all = W.config3(n_total, H, np.float32)
-    s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, lo:hi])).to(dev)
-    pid = torch.from_numpy(pid_all[lo:hi].copy()).to(dev)
-    tabd = torch.from_numpy(tab).to(dev)
-    # the next rank's inputs, kept on the host: after the timed region this rank integrates that block itself
-    # and compares what the exchange delivered for it bit for bit (`exchange.verified`)
-    plo, phi = sh.bounds[(rank + 1) % world]
-    s0_peer = np.ascontiguousarray(s0_all[:, plo:phi]) if collective else None
-    pid_peer = pid_all[plo:phi].copy() if collective else None
-    del s0_all, pid_all
-    xch = D.make_exchange(args.exchange, sh, rows=12, like=s0, handle=cp.handle()) if collective else None
+    def make_job(n_total):
+        """The workload of `n_total` rollouts: whole egos per rank (workloads.shard_egos through ShardedRollout),
+        this rank's shard resident on the device; and the NEXT rank's inputs, kept on the host: after a timed region
+        this rank integrates that block itself and compares what the exchange delivered for it bit for bit."""
+        sh = D.ShardedRollout(n_total)
+        assert sh.world == world and sh.rank == rank
+        s0_all, tab, pid_all = W.config3(n_total, H, np.float32)
+        j = SimpleNamespace(sh=sh, n_total=n_total, tab=tab, lo=sh.lo, hi=sh.hi, n_local=sh.n_local)
+        j.s0 = torch.from_numpy(np.ascontiguousarray(s0_all[:, sh.lo:sh.hi])).to(dev)
+        j.pid = torch.from_numpy(pid_all[sh.lo:sh.hi].copy()).to(dev)
+        j.tabd = torch.from_numpy(tab).to(dev)
+        j.plo, j.phi = sh.bounds[(rank + 1) % world]
+        j.s0_peer = np.ascontiguousarray(s0_all[:, j.plo:j.phi]) if collective else None
+        j.pid_peer = pid_all[j.plo:j.phi].copy() if collective else None
+        return j
 
-    def step():
-        term = cp.rollout(s0, tabd, pid)
-        if collective:
-            # the exchange step of BASELINE configs[3]: every rank ends up with all terminal states
-            # (rank-major blocks [world][12][n_pad]).  It runs beside the compute stream; the previous
-            # step's exchange is only waited for AFTER this step's rollout has been queued, so exchange
-            # k overlaps rollout k+1 (all K exchanges still complete inside the timed region: fence())
-            xch.wait()
-            xch.start(term)
-            if args.no_overlap:
+    def timed_steps(j, cpx, xch, steps, warmup, overlap=True, prewarm_ms=0.0):
+        """W untimed + K timed steps of job `j` (rollout, then the exchange when there is one), bracketed by barrier +
+        synchronize on both sides; elapsed = MAX over the ranks."""
+        def step():
+            term = cpx.rollout(j.s0, j.tabd, j.pid)
+            if xch is not None:
+                # the exchange step of BASELINE configs[3]: every rank ends up with all terminal states (rank-major
+                # blocks [world][12][n_pad]).  It runs beside the compute stream -- exchange k overlaps rollout k + 1
+                # -- and the HOST does not wait for it between steps: successive exchanges are ordered on the device
+                # (distributed.PeerExchange / AllGatherExchange.start); all K complete inside the timed region (fence)
+                xch.start(term)
+                if not overlap:
+                    xch.wait()
+            return term
+
+        def fence():
+            if xch is not None:
                 xch.wait()
-        return term
+                dist.barrier()
+            cpx.sync()
 
-    def fence():
-        if collective:
-            xch.wait()
-            dist.barrier()
-        cp.sync()
+        # A full Python garbage collection (tens of ms once torch's ~1e6 objects are alive) landing inside the
+        # timed loop stalls the launch queue: measured 0.24 -> 0.26-0.34 ms per step on the runs it hit.  The
+        # cyclic collector is paused from here to the end of the timed steps (reference counting still frees
+        # tensors).  It runs BEFORE the clock ramp: the collection itself leaves the GPU idle for ~50 ms, after
+        # which the first ~90 launches ran up to 20 % slow.
+        gc.collect()
+        gc.disable()
+        try:
+            # clock ramp (reported in the JSON as `prewarm`): the same step, untimed, for a fixed wall time
+            launches = 0
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+                for _ in range(16):
+                    cpx.rollout(j.s0, j.tabd, j.pid)   # kernel only: a wall-time loop must not contain a collective
+                launches += 16                         # (ranks would issue different numbers of them)
+                cpx.sync()
+            for _ in range(warmup):
+                step()
+            fence()
+            # ONE pair of HIP events brackets the K timed steps on the launching stream (an event pair per launch
+            # costs ~3 % of a 0.2 ms step: the markers serialise the dispatches)
+            t0 = time.perf_counter()
+            ev_a = cpx.mark()
+            for _ in range(steps):
+                term = step()
+            ev_b = cpx.mark()
+            enqueue = time.perf_counter() - t0     # host time to queue the K steps (GPU-bound when << elapsed)
+            fence()
+            elapsed = time.perf_counter() - t0
+            region_s = cpx.elapsed_s(ev_a, ev_b)
+            # per-launch durations, sampled right after the timed region (same clock state), kernel only
+            kern_ev = []
+            for _ in range(min(max(steps, 20), 100)):
+                a = cpx.mark()
+                cpx.rollout(j.s0, j.tabd, j.pid)
+                kern_ev.append((a, cpx.mark()))
+            cpx.sync()
+        finally:
+            gc.enable()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert bool(torch.isfinite(term).all()), "non-finite terminal states"
+        durs = np.array([cpx.elapsed_s(a, b) for a, b in kern_ev])
+        return SimpleNamespace(term=term, elapsed=elapsed, enqueue=enqueue, region_s=region_s, durs=durs,
+                               prewarm_launches=launches, steps=steps)
 
-    # A full Python garbage collection (tens of ms once torch's ~1e6 objects are alive) landing inside the
-    # timed loop stalls the launch queue: measured 0.24 -> 0.26-0.34 ms per step on the runs it hit.  The
-    # cyclic collector is paused from here to the end of the timed steps (reference counting still frees
-    # tensors).  It runs BEFORE the clock ramp: the collection itself leaves the GPU idle for ~50 ms, after
-    # which the first ~90 launches ran up to 20 % slow.
-    import gc
-    gc.collect()
-    gc.disable()
-    # clock ramp (reported in the JSON as `prewarm`): the same step, untimed, for a fixed wall time
-    prewarm_launches = 0
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(16):
-            cp.rollout(s0, tabd, pid)              # kernel only: a wall-time loop must not contain a collective
-        prewarm_launches += 16                     # (ranks would issue different numbers of them)
-        cp.sync()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # ONE pair of HIP events brackets the K timed steps on the launching stream (an event pair per launch
-    # costs ~3 % of a 0.2 ms step: the markers serialise the dispatches)
-    t0 = time.perf_counter()
-    ev_a = cp.mark()
-    for _ in range(args.steps):
-        term = step()
-    ev_b = cp.mark()
-    enqueue = time.perf_counter() - t0     # host time to queue the K steps (GPU-bound when << elapsed)
-    fence()
-    elapsed = time.perf_counter() - t0
-    region_s = cp.elapsed_s(ev_a, ev_b)
-    # per-launch durations, sampled right after the timed region (same clock state), kernel only
-    kern_ev = []
-    for _ in range(min(max(args.steps, 20), 100)):
-        a = cp.mark()
-        cp.rollout(s0, tabd, pid)
-        kern_ev.append((a, cp.mark()))
-    cp.sync()
-    gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert bool(torch.isfinite(term).all()), "non-finite terminal states"
+    def verify(j, cpx, xch, term):
+        """The exchanged result, checked once outside the timed region: this rank's own block came back unchanged,
+        every block is finite, and the block of the NEXT rank -- data that crossed the link -- equals, bit for bit,
+        this rank's own integration of that rank's inputs (same kernel, same code object: SURVEY 8e's shard +
+        gather identity); the verdict is the AND over all ranks.  Collective.  -> (verdict, gathered [12][n_total])"""
+        full = xch.result()
+        peer = cpx.rollout(torch.from_numpy(j.s0_peer).to(dev), j.tabd, torch.from_numpy(j.pid_peer).to(dev))
+        ok = bool(torch.equal(full[:, j.lo:j.hi], term)) and bool(torch.isfinite(full).all()) \
+            and tuple(full.shape) == (12, j.n_total) and bool(torch.equal(full[:, j.plo:j.phi], peer))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        return bool(int(okt.item())), full
+
+    VERIFIED_HOW = ("every rank: own block unchanged, all finite, next rank's block == own integration of its "
+                    "inputs (bitwise)")
+
+    # ---- the headline measurement: what `value` is -------------------------------------------------------------
+    n_total = total_rollouts(world, per_gpu, args.strong)
+    job = make_job(n_total)
+    sh, n_local, tab = job.sh, job.n_local, job.tab
+    xch = D.make_exchange(args.exchange, sh, rows=12, like=job.s0, handle=cp.handle()) if collective else None
+    m = timed_steps(job, cp, xch, args.steps, args.warmup, overlap=not args.no_overlap, prewarm_ms=args.prewarm_ms)
+    term, elapsed = m.term, m.elapsed
     gathered_ok = None
     if collective:
-        # the exchanged result, checked once outside the timed region: this rank's own block came back
-        # unchanged, every block is finite, and the block of the NEXT rank -- data that crossed the link --
-        # equals, bit for bit, this rank's own integration of that rank's inputs (same kernel, same code
-        # object: SURVEY 8e's shard + gather identity); the verdict is the AND over all ranks
-        full = xch.result()
-        peer = cp.rollout(torch.from_numpy(s0_peer).to(dev), tabd, torch.from_numpy(pid_peer).to(dev))
-        gathered_ok = bool(torch.equal(full[:, lo:hi], term)) and bool(torch.isfinite(full).all()) \
-            and tuple(full.shape) == (12, n_total) and bool(torch.equal(full[:, plo:phi], peer))
-        okt = torch.tensor([1 if gathered_ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        gathered_ok = bool(int(okt.item()))
+        gathered_ok, full = verify(job, cp, xch, term)
         if args.dump_gathered:
             np.save(os.path.join(args.dump_gathered, f"gathered_rank{rank}.npy"), full.cpu().numpy())
+        del full
 
-    durs = np.array([cp.elapsed_s(a, b) for a, b in kern_ev])
+    durs = m.durs
     kern_iso, kern_med = float(durs.mean()), float(np.median(durs))
     # the dominant kernel's average launch duration over the timed region (launch-to-launch, dispatch gaps
     # included); with an exchange inside the step the isolated sample is the kernel's own time
-    kern_s = kern_iso if collective else region_s / args.steps
+    kern_s = kern_iso if collective else m.region_s / args.steps
     units = n_total * H * args.steps
     steps_per_launch = n_local * H
     out = {
@@ -425,9 +462,9 @@ def run(args, compute_factory=None):
         "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rollouts_per_s": n_total * args.steps / elapsed,
-        "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
+        "host_enqueue_ms_per_step": m.enqueue / args.steps * 1e3,
         "host_wait": "poll" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupt",
-        "prewarm": {"ms": args.prewarm_ms, "launches": prewarm_launches,
+        "prewarm": {"ms": args.prewarm_ms, "launches": m.prewarm_launches,
                     "why": "GPU clock ramp after idle, before the W untimed warm-up steps"},
         # the same job without the exchange step (SURVEY 8d config 4 asks for both): rank 0's kernel time only
         "value_excluding_collective": n_total * H / kern_s,
@@ -435,8 +472,7 @@ def run(args, compute_factory=None):
         "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
         "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
                                                  "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok,
-                                                 "verified_how": "every rank: own block unchanged, all finite, next "
-                                                                 "rank's block == own integration of its inputs (bitwise)",
+                                                 "verified_how": VERIFIED_HOW,
                                                  "requested": args.exchange, "fallback_reason": xch.fallback_reason},
         "config": {
             "workload": f"BASELINE configs[2]: {per_gpu} rollouts per GPU (ego r//7, lattice path r%7; whole egos per "
@@ -459,7 +495,7 @@ def run(args, compute_factory=None):
         algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * n_local
         out["roofline"] = {
             "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / VALU_PEAK_TFLOPS, "traffic": None,
+            "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "per_gpu": True,
             "flop_per_vehicle_step": FLOP_PER_STEP, "kernel": "rollout_kernel<float,2,LDS-shared>",
             "kernel_ms": kern_s * 1e3, "kernel_ms_source": "isolated per-launch events after the timed region" if collective
             else "one HIP event pair around the K timed launches / K",
@@ -475,27 +511,127 @@ def run(args, compute_factory=None):
         ach = algo_bytes / kern_s / 1e9
         out["roofline_hbm"] = {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": cf.get("traffic"),
+            "frac": ach / HBM_PEAK_GBS, "traffic": cf.get("traffic"), "per_gpu": True,
             "algorithmic_bytes_per_launch": algo_bytes,
         }
+
+    # ---- everything below is OUTSIDE the timed region and only adds keys to the line ---------------------------
+    # One `python bench.py --gpus N` is all an 8-GPU lease gets, so the default N > 1 line also carries what
+    # north_star and SURVEY 8(d) config 4 ask for: both exchanges side by side, the fixed-65536 split, the CPU
+    # baseline.  The headline line is complete at this point: should one of the sections below hang (a rank lost
+    # inside a collective), a watchdog prints the line as it stands -- with `sections_timed_out` -- and ends the rank.
+    printed = threading.Lock()
+
+    def emit():
+        if printed.acquire(blocking=False) and rank == 0:
+            print(json.dumps(out), flush=True)
+
+    def bail():
+        # (timer thread; the main thread may be adding keys: retry the dump rather than lose the line)
+        out["sections_timed_out"] = {"after_s": args.sections_timeout_s, "in": out.pop("_section", None)}
+        for _ in range(20):
+            try:
+                emit()
+                break
+            except RuntimeError:
+                printed.release()
+                time.sleep(0.05)
+        os._exit(0)
+
+    watchdog = None
+    if collective and not args.no_sections:
+        watchdog = threading.Timer(args.sections_timeout_s, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    strong_full = None
+    if collective and not args.no_sections:
+        xch.close()
+        xch = None
+        k_ab, w_ab = max(1, args.steps // 2), max(1, args.warmup // 2)
+        # (a) the two exchanges, K/2 steps each on the headline's job: the collective north_star names (RCCL
+        # all_gather_into_tensor) and the peer copies, fresh objects in the same ranks
+        out["_section"] = "exchange_ab"
+        ab = {"steps": k_ab, "warmup": w_ab, "no_exchange_kernel_ms": kern_iso * 1e3}
+        for kind in ("rccl", "p2p"):
+            try:
+                if kind == "rccl":
+                    x, why = D.AllGatherExchange(sh, 12, job.s0), None
+                elif cp.handle() is None:
+                    x, why = None, "no library handle (CPU stand-in)"
+                else:
+                    x, why = D.PeerExchange.try_create(sh, 12, job.s0, cp.handle())
+                if x is None:
+                    ab[kind] = {"available": False, "reason": why}
+                    continue
+                r = timed_steps(job, cp, x, k_ab, w_ab)
+                ok, _ = verify(job, cp, x, r.term)
+                ab[kind] = {"available": True, "kind": x.kind, "ms_per_step": r.elapsed / k_ab * 1e3,
+                            "host_enqueue_ms_per_step": r.enqueue / k_ab * 1e3, "verified": ok,
+                            "value": n_total * H * k_ab / r.elapsed}
+                x.close()
+            except Exception as e:                      # noqa: BLE001 -- the headline line must survive
+                ab[kind] = {"available": False, "error": repr(e)}
+        out["exchange_ab"] = ab
+        # (b) BASELINE configs[3] as worded: the FIXED 65536 rollouts split over the ranks by whole egos, lane kernel
+        # (bitwise the single-GPU result) and wheel-parallel kernel (the labelled second number for small shards)
+        out["_section"] = "strong"
+        n_s = total_rollouts(world, per_gpu, True)
+        st = {"rollouts_total": n_s, "steps": k_ab, "warmup": w_ab, "verified_how": VERIFIED_HOW,
+              "note": "fixed-N split: one GPU already runs 65536 rollouts at one wave per SIMD, so the lane kernel's "
+                      "time per launch does not shrink with the shard (occupancy-capped, SURVEY 8e); the "
+                      "wheel-parallel kernel shortens the serial chain for small shards"}
+        try:
+            job_s = job if n_s == n_total else make_job(n_s)
+            st["shards"] = [list(b) for b in job_s.sh.bounds]
+            for name, lanes_s in (("lane", 1), ("wheel_parallel", 4)):
+                cpx = cp if lanes_s == lanes else cp.with_lanes(lanes_s)
+                x = D.make_exchange(args.exchange, job_s.sh, rows=12, like=job_s.s0, handle=cpx.handle())
+                r = timed_steps(job_s, cpx, x, k_ab, w_ab)
+                ok, full = verify(job_s, cpx, x, r.term)
+                st[name] = {"ms_per_step": r.elapsed / k_ab * 1e3, "value": n_s * H * k_ab / r.elapsed,
+                            "kernel_ms": float(r.durs.mean()) * 1e3, "exchange": x.kind, "verified": ok,
+                            "lanes_per_rollout": lanes_s, "rollouts_per_gpu": job_s.n_local}
+                if name == "lane" and ok:
+                    strong_full = full.cpu().numpy()
+                del full
+                x.close()
+        except Exception as e:                          # noqa: BLE001
+            st["error"] = repr(e)
+        out["strong"] = st
+        out.pop("_section", None)
+
+    if rank == 0:
         if world == 1 and on_gpu and not args.no_extra and not args.strong:
-            out["extra"] = extra_configs(cp.vm, W, torch, dev, s0, tab, pid)
-        if world == 1 and on_gpu and not args.no_cpu_baseline:
-            full_size = not args.strong and per_gpu == N_PER_GPU and H == HORIZON
-            term_c = None
-            if full_size:
-                s22 = torch.cat([s0, torch.zeros((10, s0.shape[1]), dtype=s0.dtype, device=dev)])
-                term_c = cp.vm.rollout(s22, tabd, path_id=pid)[:12].cpu().numpy()
-            cb = cpu_baseline(W, term.cpu().numpy() if full_size else None, term_c)
+            out["extra"] = extra_configs(cp.vm, W, torch, dev, job.s0, tab, job.pid)
+        if not args.no_cpu_baseline and (on_gpu or world > 1):
+            # rank 0's host, the other ranks idle at the barrier below.  BASELINE's second metric, the fp32 state
+            # error against the fp64 oracle, needs the full configs[2] result: the headline's own terminal states on
+            # one GPU, the gathered fixed-65536 split (bitwise the same thing) on more
+            out["_section"] = "cpu_baseline"
+            full_size = per_gpu == N_PER_GPU and H == HORIZON
+            gpu_term = term_c = None
+            if full_size and world == 1 and not args.strong:
+                gpu_term = term.cpu().numpy()
+                if on_gpu:
+                    s22 = torch.cat([job.s0, torch.zeros((10, job.s0.shape[1]), dtype=job.s0.dtype, device=dev)])
+                    term_c = cp.vm.rollout(s22, job.tabd, path_id=job.pid)[:12].cpu().numpy()
+            elif full_size and strong_full is not None:
+                gpu_term = strong_full
+            cb = cpu_baseline(W, gpu_term, term_c)
             err = cb.pop("fp32_state_error")
             if err is not None:
                 out["fp32_state_error"] = err
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["value"] / cb["value"]
-        print(json.dumps(out), flush=True)
+            out.pop("_section", None)
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
     if collective:
         dist.barrier()
-        xch.close()
+        if xch is not None:
+            xch.close()
         dist.destroy_process_group()
     return out
 

@@ -158,7 +158,11 @@ int vdyn_step_f32_host(VdynHandle *h, int64_t n, const float *state_in, const fl
  * state0 [12][n]; ctrl per `layout` (VDYN_CTRL_*): [H][k][n], or table [P][H][k]
  * with path_id [n] (values in [0,P)); mu4 = 4 host doubles used when k = 2 (NULL -> 1).
  * -> terminal [12][n]; traj (nullable) [H / traj_stride][12][n] = the state after
- *    steps traj_stride, 2*traj_stride, ...                                             */
+ *    steps traj_stride, 2*traj_stride, ...  One trajectory ROW (12 n values) may span at most
+ *    2^31 bytes (fp32: n <= 44.7 M, fp64: n <= 22.3 M; VDYN_ERR_ARG beyond -- split the batch):
+ *    the kernels address a row with a 64-bit base and 32-bit offsets.  The same holds for
+ *    vdyn_rollout_spiral_*, vdyn_rollout_fleet_* and, with 16 / 45 values per vehicle, for the
+ *    log / DataLog rows of vdyn_closed_loop_*.                                          */
 int vdyn_rollout_f64_dev(VdynHandle *h, int64_t n, int32_t H, const double *state0,
                          const double *ctrl, int k, int layout, const int32_t *path_id, int32_t P,
                          double dt, const double *mu4, double *terminal, double *traj,
@@ -497,11 +501,19 @@ int vdyn_xchg_open(VdynHandle *h, const VdynIpcHandle *peer, void **peer_ptr);
 int vdyn_xchg_close(VdynHandle *h, void *peer_ptr);
 /* Copy `bytes` from src (this device) to dst[i] + dst_offset for i < n_dst, on the handle's copy
  * streams, after everything enqueued so far on `after_stream` (the compute stream; NULL = default).
- * Returns without waiting.  At most 64 destinations; one push in flight per handle (an error
- * otherwise: vdyn_xchg_wait() first).                                                           */
+ * Returns without waiting.  At most 64 destinations.  Any number of pushes may be in flight: they
+ * follow each other on the device (destination i always uses the same in-order copy stream, so of
+ * two pushes into the same slot the later one lands last).  What the CALLER must keep is the source
+ * block, until the push's copies have read it: vdyn_xchg_fence orders its reuse on the device.
+ * On an error, copies already queued have been waited for before the call returns.             */
 int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
                    uint64_t bytes, void *after_stream);
-/* Block the host until this handle's pushes have landed (a no-op when none is in flight). */
+/* Make `stream` wait -- on the device; the host does not block -- until the copies of the push issued
+ * `lag` pushes before the latest one have finished (lag 0: the latest push; 0 <= lag < 4).  After
+ * it, work enqueued on `stream` may overwrite (or the allocator may hand out) that push's source.
+ * A no-op when no such push exists.                                                             */
+int vdyn_xchg_fence(VdynHandle *h, void *stream, int32_t lag);
+/* Block the host until all of this handle's pushes have landed (a no-op when none is in flight). */
 int vdyn_xchg_wait(VdynHandle *h);
 
 #ifdef __cplusplus

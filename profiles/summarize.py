@@ -41,6 +41,32 @@ def loaded_build_id():
         return None
 
 
+def code_object_registers(rocprof_kernel_name):
+    """vgpr / agpr / sgpr / scratch / spill counts of the kernel from the CODE OBJECT's metadata inside the built
+    library (tools/isa/code_object_meta.py).  rocprofv3's VGPR_Count column is not that number on gfx950 (108 for the
+    headline kernel whose code object says 212): it is kept under `rocprofv3_*` names only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools", "isa"))
+    try:
+        import code_object_meta as M
+        global _META
+        try:
+            _META
+        except NameError:
+            _META = M.kernel_meta()
+        m = M.lookup(_META, rocprof_kernel_name)
+    except Exception as e:                      # noqa: BLE001 -- the summary still carries the counters
+        return {"code_object_registers_error": repr(e)}
+    if m is None:
+        return {"code_object_registers_error": "kernel not found in the library's code objects"}
+    total = m["vgpr"] + m["agpr"]
+    return {"vgpr": m["vgpr"], "agpr": m["agpr"], "sgpr": m["sgpr"], "scratch_bytes": m["scratch_bytes"],
+            "vgpr_spills": m["vgpr_spills"], "sgpr_spills_to_vgpr_lanes": m["sgpr_spills"],
+            # gfx950: 512 unified registers per SIMD lane, allocated in blocks of 8
+            "occupancy_waves_per_simd": max(1, min(8, 512 // max(8, -(-total // 8) * 8))),
+            "registers_source": "code object metadata (tools/isa/code_object_meta.py)"}
+
+
 summary = {"tag": tag, "build_id": loaded_build_id(), "kernel": None}
 ks = find("kt", "*kernel_stats.csv")
 if ks:
@@ -74,14 +100,15 @@ if kt:
         summary["median_ns"] = float(dur[len(dur) // 2])
     for r in csv.DictReader(open(kt)):
         if KERNEL in r["Kernel_Name"]:
-            summary["vgpr"] = int(r["VGPR_Count"])
-            summary["accum_vgpr"] = int(r["Accum_VGPR_Count"])
-            summary["sgpr"] = int(r["SGPR_Count"])
+            summary["rocprofv3_vgpr_count"] = int(r["VGPR_Count"])
+            summary["rocprofv3_accum_vgpr_count"] = int(r["Accum_VGPR_Count"])
+            summary["rocprofv3_sgpr_count"] = int(r["SGPR_Count"])
             summary["static_lds_bytes"] = int(r["LDS_Block_Size"])     # rocprofv3 reports the static part only
             # dynamic LDS of the bench launch, from the launch arithmetic (vdyn_kernels.hip, launch_rollout_impl):
             # the k = 2 control table is staged 4 wide -- (delta, torque, sin, cos) -- for P = 7 paths x H = 200 steps
             summary["dynamic_lds_bytes"] = 7 * 4 * 4 * 200
             summary["scratch_bytes"] = int(r["Scratch_Size"])
+            summary.update(code_object_registers(r["Kernel_Name"]))
             summary["grid"] = int(r["Grid_Size_X"])
             summary["workgroup"] = int(r["Workgroup_Size_X"])
             break

@@ -36,6 +36,32 @@ def loaded_build_id():
         return None
 
 
+def code_object_registers(rocprof_kernel_name):
+    """vgpr / agpr / sgpr / scratch / spill counts of the kernel from the CODE OBJECT's metadata inside the built
+    library (tools/isa/code_object_meta.py).  rocprofv3's VGPR_Count column is not that number on gfx950 (108 for the
+    headline kernel whose code object says 212): it is kept under `rocprofv3_*` names only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools", "isa"))
+    try:
+        import code_object_meta as M
+        global _META
+        try:
+            _META
+        except NameError:
+            _META = M.kernel_meta()
+        m = M.lookup(_META, rocprof_kernel_name)
+    except Exception as e:                      # noqa: BLE001 -- the summary still carries the counters
+        return {"code_object_registers_error": repr(e)}
+    if m is None:
+        return {"code_object_registers_error": "kernel not found in the library's code objects"}
+    total = m["vgpr"] + m["agpr"]
+    return {"vgpr": m["vgpr"], "agpr": m["agpr"], "sgpr": m["sgpr"], "scratch_bytes": m["scratch_bytes"],
+            "vgpr_spills": m["vgpr_spills"], "sgpr_spills_to_vgpr_lanes": m["sgpr_spills"],
+            # gfx950: 512 unified registers per SIMD lane, allocated in blocks of 8
+            "occupancy_waves_per_simd": max(1, min(8, 512 // max(8, -(-total // 8) * 8))),
+            "registers_source": "code object metadata (tools/isa/code_object_meta.py)"}
+
+
 result = {"tag": tag, "build_id": loaded_build_id(), "cases": {}}
 for mf in sorted(glob.glob(os.path.join(out, "*", "manifest.json"))):
     base = os.path.dirname(mf)
@@ -54,9 +80,12 @@ for mf in sorted(glob.glob(os.path.join(out, "*", "manifest.json"))):
         for r in csv.DictReader(open(kt)):
             if key in r["Kernel_Name"]:
                 durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-                s.update(vgpr=int(r["VGPR_Count"]), accum_vgpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
+                s.update(rocprofv3_vgpr_count=int(r["VGPR_Count"]), rocprofv3_accum_vgpr_count=int(r["Accum_VGPR_Count"]),
+                         rocprofv3_sgpr_count=int(r["SGPR_Count"]),
                          static_lds_bytes=int(r["LDS_Block_Size"]), scratch_bytes=int(r["Scratch_Size"]),
                          grid=int(r["Grid_Size_X"]), workgroup=int(r["Workgroup_Size_X"]))
+                if "registers_source" not in s:
+                    s.update(code_object_registers(r["Kernel_Name"]))
         if durs:      # the timed launches are the last `launches` of the trace (after the warm-up loop)
             tail = durs[-int(man["launches"]):]
             s["timed_avg_ns"] = sum(tail) / len(tail)
@@ -103,6 +132,6 @@ for mf in sorted(glob.glob(os.path.join(out, "*", "manifest.json"))):
 with open(os.path.join(out, "summary", f"{tag}_kernels_pmc_summary.json"), "w") as f:
     json.dump(result, f, indent=1)
 for k, s in result["cases"].items():
-    print(k, {x: s.get(x) for x in ("timed_avg_ns", "vgpr", "valu_insts_per_wave_per_rk4_step", "wave_cycles_per_valu_inst",
+    print(k, {x: s.get(x) for x in ("timed_avg_ns", "vgpr", "agpr", "valu_insts_per_wave_per_rk4_step", "wave_cycles_per_valu_inst",
                                     "wait_any_frac_of_wave_cycles", "hbm_bytes_per_launch", "hbm_frac_counter",
                                     "hbm_bytes_over_algorithmic", "steps_per_s")})

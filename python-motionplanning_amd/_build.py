@@ -6,6 +6,7 @@ travels to the GPU box with the working tree.
 """
 from __future__ import annotations
 
+import json
 import os
 import shutil
 import subprocess
@@ -60,25 +61,43 @@ def source_hash(extra_flags=()):
     return h.hexdigest()[:16]
 
 
+def _read_id():
+    """(build id, extra flags) the library beside LIB_PATH was built with; (None, ()) when there is no record."""
+    try:
+        lines = open(LIB_PATH + ".id").read().splitlines()
+    except OSError:
+        return None, ()
+    extra = tuple(json.loads(lines[1])) if len(lines) > 1 and lines[1].strip() else ()
+    return (lines[0].strip() if lines else None), extra
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
-    # the id the library was built with (written beside it at link time) against the sources as they are now:
-    # catches an edit made WHILE a build was running, which modification times alone miss
-    try:
-        if open(LIB_PATH + ".id").read().strip() != source_hash():
-            return True
-    except OSError:
-        return True
-    # the hash covers every source, header and flag: a file that is merely NEWER than the library (a checkout, a copy
-    # onto the GPU box) with the same content is not a reason to compile for four minutes
-    return False
+    # the id the library was built with (written beside it at link time, together with any extra flags of that build)
+    # against the sources as they are now: catches an edit made WHILE a build was running, which modification times
+    # alone miss.  The hash covers every source, header and flag: a file that is merely NEWER than the library (a
+    # checkout, a copy onto the GPU box) with the same content is not a reason to compile for four minutes.
+    built, extra = _read_id()
+    return built is None or built != source_hash(extra)
+
+
+def _content_hash(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for f in paths:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False, extra_flags=()):
     """Compile every HIP source of the package (in parallel, one object each) and link
     libvdyn_hip.so."""
-    if not force and not is_stale():
+    extra_flags = tuple(extra_flags)
+    if not force and not extra_flags and not is_stale():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     hipcc = hipcc_path()
@@ -98,18 +117,23 @@ def build(force=False, verbose=False, extra_flags=()):
         cmd = [hipcc, *HIPCC_FLAGS, *flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if src == "vdyn_capi.hip":
             cmd.insert(1, f'-DVDYN_BUILD_ID="{build_id}"')
-        # an object is reused when it is newer than everything it was compiled from and its command line is the same
+        # an object is reused when its command line AND the content of everything it was compiled from are what its
+        # stamp records.  The content hash is taken BEFORE compiling: a source edited while its unit compiles leaves
+        # a stamp that no longer matches, whatever the modification times say.
         stamp = obj + ".cmd"
-        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd) \
-                and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps_of(src)):
+        want = " ".join(cmd) + "\n" + _content_hash(deps_of(src))
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
             return obj
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        if os.path.exists(stamp):
+            os.remove(stamp)
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout)
-        with open(stamp, "w") as f:
-            f.write(" ".join(cmd))
+        with open(stamp + ".tmp", "w") as f:
+            f.write(want)
+        os.replace(stamp + ".tmp", stamp)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
@@ -120,9 +144,14 @@ def build(force=False, verbose=False, extra_flags=()):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout)
+    # the id first goes stale-side: a crash between the two renames leaves a library whose id does not match (rebuilt
+    # next time), never a new library under the old id
+    if os.path.exists(LIB_PATH + ".id"):
+        os.remove(LIB_PATH + ".id")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    with open(LIB_PATH + ".id", "w") as f:
-        f.write(build_id + "\n")
+    with open(LIB_PATH + ".id.tmp", "w") as f:
+        f.write(build_id + "\n" + (json.dumps(list(extra_flags)) if extra_flags else "") + "\n")
+    os.replace(LIB_PATH + ".id.tmp", LIB_PATH + ".id")
     return LIB_PATH
 
 

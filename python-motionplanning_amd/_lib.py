@@ -126,6 +126,7 @@ SIGNATURES.update({
     "vdyn_xchg_open": (_int, [_vp, C.POINTER(VdynIpcHandle), C.POINTER(_vp)]),
     "vdyn_xchg_close": (_int, [_vp, _vp]),
     "vdyn_xchg_push": (_int, [_vp, C.POINTER(_vp), _i32, _u64, _vp, _u64, _vp]),
+    "vdyn_xchg_fence": (_int, [_vp, _vp, _i32]),
     "vdyn_xchg_wait": (_int, [_vp]),
 })
 
@@ -191,6 +192,12 @@ class Handle:
             raise VdynError(rc, msg.decode() if msg else "vdyn_create failed")
         self.device = int(device)
         self._key = params.key()
+        # handle-wide state (vdyn_set_option) is set, used by a launch and reset under this lock: two threads
+        # sharing a VehicleModel must not see each other's VDYN_OPT_STATE_ROWS (a 12-row call launched while the
+        # option says 22 would read and write 22 rows of 12-row buffers).  The C handle itself stays single-threaded
+        # (include/vdyn.h); this only keeps the Python shim's own set / launch / reset sequences apart.
+        import threading
+        self.lock = threading.RLock()
 
     def set_params(self, params: VdynParams, key=None):
         key = params.key() if key is None else key

@@ -32,9 +32,11 @@ struct VdynHandle {
     // (round robin beyond kCopyStreams), so that the copies to different peers can use different SDMA engines and
     // xGMI links at the same time instead of queueing behind each other
     static constexpr int kCopyStreams = 8;
+    static constexpr int kPushRing = 4;     // pushes whose completion events are kept (vdyn_xchg_fence looks back this far)
     hipStream_t copy_stream[kCopyStreams] = {};
-    hipEvent_t ev_ready = nullptr, ev_done[kCopyStreams] = {};
-    int push_streams = 0;           // streams the push in flight used (0: none in flight)
+    hipEvent_t ev_ready = nullptr, ev_done[kPushRing][kCopyStreams] = {};
+    int push_streams = 0;           // copy streams in use (0: no push issued since the last vdyn_xchg_wait)
+    int64_t pushes = 0;             // pushes issued over the handle's life; push k records ev_done[k % kPushRing]
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -183,7 +185,8 @@ void vdyn_destroy(VdynHandle *h)
     if (h->d_count) (void)hipFree(h->d_count);
     for (int i = 0; i < VdynHandle::kCopyStreams; ++i) {
         if (h->copy_stream[i]) { (void)hipStreamSynchronize(h->copy_stream[i]); (void)hipStreamDestroy(h->copy_stream[i]); }
-        if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
+        for (int k = 0; k < VdynHandle::kPushRing; ++k)
+            if (h->ev_done[k][i]) (void)hipEventDestroy(h->ev_done[k][i]);
     }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     delete h;
@@ -270,22 +273,52 @@ int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_
     for (int i = 0; i < n_dst; ++i)
         if (!dst[i]) return h->fail(VDYN_ERR_ARG, "xchg_push: null destination");
     VDYN_HIP(h, hipSetDevice(h->device));
-    if (h->push_streams != 0) return h->fail(VDYN_ERR_ARG, "xchg_push: vdyn_xchg_wait() for the previous push first");
     const int ns = std::min<int>(n_dst, VdynHandle::kCopyStreams);
     if (!h->ev_ready) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     for (int i = 0; i < ns; ++i) {
-        if (h->copy_stream[i]) continue;
-        VDYN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream[i], hipStreamNonBlocking));
-        VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+        if (!h->copy_stream[i]) VDYN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream[i], hipStreamNonBlocking));
+        for (int k = 0; k < VdynHandle::kPushRing; ++k)
+            if (!h->ev_done[k][i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done[k][i], hipEventDisableTiming));
     }
-    VDYN_HIP(h, hipEventRecord(h->ev_ready, (hipStream_t)after_stream));          // the block is complete ...
-    for (int i = 0; i < ns; ++i)
-        VDYN_HIP(h, hipStreamWaitEvent(h->copy_stream[i], h->ev_ready, 0));       // ... before any copy reads it
-    for (int i = 0; i < n_dst; ++i)
-        VDYN_HIP(h, hipMemcpyAsync(static_cast<char *>(dst[i]) + dst_offset, src, bytes, hipMemcpyDeviceToDevice,
-                                   h->copy_stream[i % ns]));
-    for (int i = 0; i < ns; ++i) VDYN_HIP(h, hipEventRecord(h->ev_done[i], h->copy_stream[i]));
-    h->push_streams = ns;
+    // Pushes follow each other on the DEVICE: push k + 1's copies sit behind push k's on the same in-order copy
+    // streams (a destination always maps to the same stream, so the later block lands last), and what the caller
+    // has to protect -- the source block, until the copies have read it -- is a device-side wait too
+    // (vdyn_xchg_fence).  The host never blocks here.
+    hipEvent_t *done = h->ev_done[h->pushes % VdynHandle::kPushRing];
+    hipError_t e = hipEventRecord(h->ev_ready, (hipStream_t)after_stream);           // the block is complete ...
+    for (int i = 0; i < ns && e == hipSuccess; ++i)
+        e = hipStreamWaitEvent(h->copy_stream[i], h->ev_ready, 0);                   // ... before any copy reads it
+    int queued = 0;
+    for (int i = 0; i < n_dst && e == hipSuccess; ++i) {
+        e = hipMemcpyAsync(static_cast<char *>(dst[i]) + dst_offset, src, bytes, hipMemcpyDeviceToDevice,
+                           h->copy_stream[i % ns]);
+        if (e == hipSuccess) ++queued;
+    }
+    for (int i = 0; i < ns && e == hipSuccess; ++i) e = hipEventRecord(done[i], h->copy_stream[i]);
+    if (e != hipSuccess) {
+        // some copies may be queued and still read `src` / write the peers' slots: let them finish before the caller
+        // frees or closes anything on this error (best effort: the streams' own errors are not the one reported)
+        if (queued > 0)
+            for (int i = 0; i < ns; ++i) (void)hipStreamSynchronize(h->copy_stream[i]);
+        return h->fail_hip("xchg_push", e);
+    }
+    h->push_streams = std::max(h->push_streams, ns);
+    ++h->pushes;
+    return VDYN_OK;
+}
+
+int vdyn_xchg_fence(VdynHandle *h, void *stream, int32_t lag)
+{
+    if (!h) return VDYN_ERR_ARG;
+    if (lag < 0 || lag >= VdynHandle::kPushRing)
+        return h->fail(VDYN_ERR_ARG, "xchg_fence: lag must be in [0, " + std::to_string(VdynHandle::kPushRing) + ")");
+    const int64_t k = h->pushes - 1 - lag;                      // the push to wait for
+    if (k < 0 || h->push_streams == 0) return VDYN_OK;          // nothing that old (or everything already waited for)
+    VDYN_HIP(h, hipSetDevice(h->device));
+    for (int i = 0; i < h->push_streams; ++i) {
+        hipEvent_t ev = h->ev_done[k % VdynHandle::kPushRing][i];
+        if (ev) VDYN_HIP(h, hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+    }
     return VDYN_OK;
 }
 
@@ -294,7 +327,7 @@ int vdyn_xchg_wait(VdynHandle *h)
     if (!h) return VDYN_ERR_ARG;
     if (h->push_streams == 0) return VDYN_OK;
     VDYN_HIP(h, hipSetDevice(h->device));
-    for (int i = 0; i < h->push_streams; ++i) VDYN_HIP(h, hipEventSynchronize(h->ev_done[i]));
+    for (int i = 0; i < h->push_streams; ++i) VDYN_HIP(h, hipStreamSynchronize(h->copy_stream[i]));   // in order: every push
     h->push_streams = 0;
     return VDYN_OK;
 }
@@ -320,6 +353,12 @@ int planar_model_dev(VdynHandle *h, int64_t n, const T *state, const T *ctrl12, 
     return VDYN_OK;
 }
 
+// The lane kernels write trajectory / log / DataLog rows through RowWriter (vdyn_kernels.hip): wave-uniform 64-bit row
+// base + 32-bit column and lane offsets.  A row of `cols` columns must therefore span at most 2^31 bytes
+// (fp32 trajectories: n <= 44.7 M rollouts; fp32 DataLog: n <= 11.9 M vehicles) -- split larger batches.
+template <typename T>
+static bool row_writer_fits(int64_t n, int cols) { return (int64_t)cols * n * (int64_t)sizeof(T) <= ((int64_t)1 << 31); }
+
 template <typename T>
 int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, const char *who)
 {
@@ -336,6 +375,8 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     if (a.layout == VDYN_CTRL_SHARED && (!a.path_id || a.P <= 0))
         return h->fail(VDYN_ERR_ARG, w + ": shared controls need path_id and P > 0");
     if (a.traj && a.traj_stride <= 0) return h->fail(VDYN_ERR_ARG, w + ": traj needs traj_stride > 0");
+    if (a.traj && !row_writer_fits<T>(a.n, 12))
+        return h->fail(VDYN_ERR_ARG, w + ": a trajectory row (12 n values) must not exceed 2^31 bytes; split the batch");
     VDYN_HIP(h, hipSetDevice(h->device));
     vdyn::RolloutArgs<T> b = a;
     b.state_rows = h->state_rows;
@@ -368,6 +409,8 @@ int rollout_spiral_dev(VdynHandle *h, int64_t n, int32_t H, const T *state0, con
     if (n == 0) return VDYN_OK;
     if (!state0 || !spiral || !terminal) return h->fail(VDYN_ERR_ARG, "rollout_spiral: null buffer");
     if (traj && traj_stride <= 0) return h->fail(VDYN_ERR_ARG, "rollout_spiral: traj needs traj_stride > 0");
+    if (traj && !row_writer_fits<T>(n, 12))
+        return h->fail(VDYN_ERR_ARG, "rollout_spiral: a trajectory row (12 n values) must not exceed 2^31 bytes; split the batch");
     const double half_pi = 1.5707963267948966;
     const double tan_max = max_steer >= half_pi ? INFINITY : std::tan(max_steer);
     VDYN_HIP(h, hipSetDevice(h->device));
@@ -432,6 +475,8 @@ int rollout_fleet_dev(VdynHandle *h, vdyn::RolloutArgs<T> a, const VdynParams *c
     if (!a.state0 || !a.terminal || !a.vehicle_id || (a.H > 0 && !a.ctrl) ||
         (a.layout == VDYN_CTRL_SHARED && (!a.path_id || a.P <= 0)) || (a.traj && a.traj_stride <= 0))
         return h->fail(VDYN_ERR_ARG, "rollout_fleet: null buffer or bad traj_stride");
+    if (a.traj && !row_writer_fits<T>(a.n, 12))
+        return h->fail(VDYN_ERR_ARG, "rollout_fleet: a trajectory row (12 n values) must not exceed 2^31 bytes; split the batch");
     VDYN_HIP(h, hipSetDevice(h->device));
     const size_t bytes = sizeof(T) * (size_t)vdyn::fleet_table_len<T>(a.V);
     if (bytes > h->d_fleet_bytes) {
@@ -736,6 +781,9 @@ int closed_loop_check(VdynHandle *h, const VdynCtrlGains *g, const vdyn::ClosedL
     if (!a.state0 || !a.cstate0 || !a.wp || !a.wcount || !a.path_id || !a.cstate)
         return h->fail(VDYN_ERR_ARG, w + ": null buffer");
     if (update_only ? !a.ctrl_out : !a.terminal) return h->fail(VDYN_ERR_ARG, w + ": null output buffer");
+    if ((a.datalog && !row_writer_fits<T>(a.n, 45)) || (a.log && !row_writer_fits<T>(a.n, 16)))
+        return h->fail(VDYN_ERR_ARG, w + ": a log row (16 n values) / DataLog row (45 n values) must not exceed 2^31 bytes; "
+                                         "split the batch");
     return VDYN_OK;
 }
 

@@ -1044,9 +1044,16 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
     }
     T he;                                                                  // :122-123
     if constexpr (sizeof(T) == 4) {
-        // the segment direction turned into the vehicle's frame first: atan2 of (cross, dot) IS the wrapped difference
+        // the segment direction turned into the vehicle's frame first: atan2 of (cross, dot) IS the wrapped difference.
+        // A zero-length segment (a closed path whose last waypoint repeats the first, a one-waypoint table, a
+        // duplicated waypoint) has the reference's arctan2(0, 0) = 0 as its heading (:109-120), i.e. the wrapped
+        // -yaw = atan2(-sin yaw, cos yaw): (cross, dot) of the unit vector along +x, not the atan2(+-0, +-0) of the
+        // rotated zero vector (0 or +-pi by the signs of sin / cos yaw)
         const T dx_ = bx_ - ax_, dy_ = by_ - ay_;
-        he = L::atan2(dy_ * cy - dx_ * sy, dx_ * cy + dy_ * sy);
+        const bool degenerate = dx_ == T(0) && dy_ == T(0);
+        const T cross = degenerate ? -sy : dy_ * cy - dx_ * sy;
+        const T dot = degenerate ? cy : dx_ * cy + dy_ * sy;
+        he = L::atan2(cross, dot);
     } else {
         he = wrap_pi<T>(L::atan2(by_ - ay_, bx_ - ax_) - yaw);
     }

@@ -7,6 +7,7 @@
 #include "vdyn_internal.hpp"
 
 #include <cstring>
+#include <utility>
 #include "vdyn_device.hpp"
 #include "vdyn_packed.hpp"
 #include "vdyn_controls.hpp"
@@ -118,6 +119,7 @@ template <typename T, int K, int LAYOUT, bool DIAG> constexpr size_t rollout_lds
 // Where the next trajectory row goes.  Row j of traj [H / stride][12][n] is the state after step (j + 1) * stride of
 // the launch: a wave-uniform countdown and a running pointer -- `(t + 1) % stride == 0` and `(t + 1) / stride` are a
 // scalar division each (no such instruction: ~30 issue slots per step for a lone wave, a tenth of the step).
+// (Per-lane pointer form: what the wheel-parallel kernel still uses; the lane kernels write through RowWriter.)
 template <typename T>
 struct TrajCursor {
     T *row;
@@ -134,6 +136,88 @@ struct TrajCursor {
     }
     __device__ __forceinline__ void next() { row += pitch; }
 };
+
+// Streaming writer of rows [rows][COLS][n] (trajectories: COLS = 12; DataLog: 45; closed-loop log: 16), one value per
+// lane and column.  What a lone wave pays for is instructions, and a store at `row + i n` from a per-lane 64-bit
+// pointer is two of them -- a dependent `v_lshl_add_u64` and the `global_store` -- twelve (forty-five) times per step.
+// Here the address is split the way the hardware adds it up for nothing:
+//   * the row's base is WAVE-UNIFORM (the workgroup's first column of the current row): a buffer descriptor in four
+//     SGPRs, advanced by the row pitch with two scalar adds per row;
+//   * the column offsets i n sizeof(T) are wave-uniform and loop-invariant: SGPRs, the store's `soffset` operand;
+//   * the lane's part is ONE 32-bit VGPR, computed once per launch
+// so a column is `buffer_store_dword vdata, voff, s[rsrc], soff offen nt` and nothing else.  More than 16 columns
+// would want more SGPRs than the step leaves: G lane offsets (each with COLS / G columns' worth folded in) x COLS / G
+// scalar offsets -- 45 = 3 x 15.
+// Idle lanes of the last workgroup shadow rollout n - 1 (they integrate it, too): they store the SAME value to the
+// SAME address as its owner, so no store needs the exec mask.
+// Host-side precondition (vdyn_capi.hip, row_writer_fits): COLS n sizeof(T) <= 2^31, every offset a positive int32.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <typename T, int COLS, int G = 1>
+struct RowWriter {
+    static_assert(COLS % G == 0, "columns per group");
+    static constexpr int PER = COLS / G;
+    char *base;                 // wave-uniform: the workgroup's first column in the current row
+    int64_t pitch;              // bytes from one row to the next
+    uint32_t voff[G];           // lane: bytes from `base` (+ the group's first column)
+    uint32_t soff[PER];         // wave-uniform: bytes of column i of a group
+    int left, stride;
+    __device__ __forceinline__ RowWriter(T *out, int64_t r, int64_t n, int stride_ = 1)
+        : base(reinterpret_cast<char *>(out + (int64_t)blockIdx.x * kBlock)), pitch((int64_t)COLS * n * (int64_t)sizeof(T)),
+          left(stride_), stride(stride_)
+    {
+        const uint32_t col = (uint32_t)n * (uint32_t)sizeof(T);
+        const uint32_t lane = (uint32_t)(r - (int64_t)blockIdx.x * kBlock) * (uint32_t)sizeof(T);
+#pragma unroll
+        for (int g = 0; g < G; ++g) voff[g] = lane + (uint32_t)(g * PER) * col;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) soff[i] = (uint32_t)i * col;
+    }
+    // after every step; true: this step's values are a row -- put() its columns, then next()
+    __device__ __forceinline__ bool due()
+    {
+        if (--left != 0) return false;
+        left = stride;
+        return true;
+    }
+    struct Row {
+        __amdgpu_buffer_rsrc_t rs;
+        const RowWriter &w;
+        template <int C>
+        __device__ __forceinline__ void put(T v) const
+        {
+            static_assert(C >= 0 && C < COLS, "column");
+            constexpr int kNt = 2;      // gfx940+: the `nt` bit -- written once, never read back by this kernel
+            if constexpr (sizeof(T) == 4)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, w.voff[C / PER], w.soff[C % PER], kNt);
+            else
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rs, w.voff[C / PER], w.soff[C % PER], kNt);
+        }
+    };
+    // raw buffer (stride 0), data format 32 bits (only read by typed instructions); num_records 2^31: every offset the
+    // precondition allows is in range
+    __device__ __forceinline__ Row row() const
+    {
+        return Row{__builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000), *this};
+    }
+    __device__ __forceinline__ void next() { base += pitch; }
+};
+// Columns C0 .. C0 + CNT - 1 of a row from value(i), i = 0 .. CNT - 1, with compile-time column numbers
+template <typename T, int C0, typename ROW, typename F, int... I>
+__device__ __forceinline__ void put_cols_seq(const ROW &row, F &&value, std::integer_sequence<int, I...>)
+{
+    (row.template put<C0 + I>((T)value(I)), ...);
+}
+template <typename T, int C0, int CNT, typename ROW, typename F>
+__device__ __forceinline__ void put_cols(const ROW &row, F &&value)
+{
+    put_cols_seq<T, C0>(row, value, std::make_integer_sequence<int, CNT>{});
+}
+// The twelve state rows of a lane kernel's packed state as one trajectory row
+template <typename T, typename ROW, typename STATE>
+__device__ __forceinline__ void put_state12(const ROW &row, const STATE &X)
+{
+    put_cols<T, 0, 12>(row, [&](int i) __attribute__((always_inline)) { return X.get(i); });
+}
 // PW (fp64, CS): the four wheels differ in C -- the per-wheel fit table goes to LDS and the step reads it from there
 // (fit_horner4_lds); otherwise the handle's one set is pinned in VGPRs (pin_tire_fit).
 // COMP (fp32, CS): state0 / terminal are [22][n], rows 12..21 the compensation terms of the state sum
@@ -172,14 +256,12 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
     constexpr int PRE = rollout_table_pre<K, LAYOUT, DIAG>() ? 1 : 0;
     if (!DIAG) eng.template init<true, CS>(P);
 
-    TrajCursor<T> tcur(TRAJ ? traj : nullptr, r, n, traj_stride);
+    RowWriter<T, 12> tw(traj, r, n, traj_stride);                  // TRAJ instances only (traj != nullptr: the launcher)
     auto dump = [&]() __attribute__((always_inline)) {
-        if (tcur.due()) {
-            if (active) {                                           // written once: streaming stores
-#pragma unroll
-                for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), tcur.row + (int64_t)i * n);
-            }
-            tcur.next();
+        if (tw.due()) {
+            const auto row = tw.row();
+            put_state12<T>(row, X);
+            tw.next();
         }
     };
     for (int t0 = 0; t0 < H; t0 += chunk) {
@@ -226,6 +308,21 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
             }
         }
+        if (!DIAG && TRAJ) {
+            // two steps per trip, the control sets ping-pong: no copies of them per step (six `v_mov_b64` in the
+            // one-step loop below, which is left with the last odd step and the diagnostic single step)
+            Ctrl<T, K> c2;
+            for (; tc + 1 < tc_n; tc += 2) {
+                fetch(c2, tc + 1);
+                VDYN_FETCH_FENCE
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                dump();
+                fetch(c, min(tc + 2, tc_n - 1));
+                VDYN_FETCH_FENCE
+                eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                dump();
+            }
+        }
         for (; tc < tc_n; ++tc) {
             Ctrl<T, K> cn;
             fetch(cn, min(tc + 1, tc_n - 1));
@@ -243,7 +340,7 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
                 eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
             }
             c = cn;
-            if (TRAJ) dump();
+            if (TRAJ && traj != nullptr) dump();                    // DIAG launches come here without a trajectory
         }
     }
 
@@ -317,15 +414,13 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
             one_step(t + 3);
         }
     }
-    TrajCursor<T> tcur(TRAJ ? traj : nullptr, r, n, traj_stride);
+    RowWriter<T, 12> tw(traj, r, n, traj_stride);                  // TRAJ instances only (traj != nullptr: the launcher)
     for (; t < H; ++t) {
         one_step(t);
-        if (TRAJ && tcur.due()) {
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) __builtin_nontemporal_store(X.get(i), tcur.row + (int64_t)i * n);
-            }
-            tcur.next();
+        if (TRAJ && tw.due()) {
+            const auto row = tw.row();
+            put_state12<T>(row, X);
+            tw.next();
         }
     }
     if (active) {
@@ -401,7 +496,7 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
     StepEngine<T> eng;
     eng.template init<false, CS>(P);   // per-lane constants
 
-    TrajCursor<T> tcur(traj, r, n, traj_stride);
+    RowWriter<T, 12> tw(traj, r, n, traj_stride);
     for (int t0 = 0; t0 < H; t0 += chunk) {
         const int tc_n = min(chunk, H - t0);
         if (LAYOUT == 1) {
@@ -422,15 +517,12 @@ rollout_fleet_kernel(const T *__restrict__ fleet, int V, const int *__restrict__
             fetch(cn, min(tc + 1, tc_n - 1));          // behind this step (see rollout_kernel)
             eng.template advance<K == 2, CS>(P, s, ax, ay, c.delta, c.tq, c.mu, h);
             c = cn;
-            if (tcur.due()) {
-                if (active) {                          // written once: streaming stores
-                    T *row = tcur.row;
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) __builtin_nontemporal_store(s[i], row + (int64_t)i * n);
-                    __builtin_nontemporal_store(ax, row + 10 * n);
-                    __builtin_nontemporal_store(ay, row + 11 * n);
-                }
-                tcur.next();
+            if (traj != nullptr && tw.due()) {         // wave-uniform
+                const auto row = tw.row();
+                row.template put<0>(s[0]); row.template put<1>(s[1]); row.template put<2>(s[2]); row.template put<3>(s[3]);
+                row.template put<4>(s[4]); row.template put<5>(s[5]); row.template put<6>(s[6]); row.template put<7>(s[7]);
+                row.template put<8>(s[8]); row.template put<9>(s[9]); row.template put<10>(ax); row.template put<11>(ay);
+                tw.next();
             }
         }
     }
@@ -963,6 +1055,8 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
 
     int until_update = (ctrl_every - phase % ctrl_every) % ctrl_every;   // steps until (phase + t) % ctrl_every == 0
     int t = 0;
+    RowWriter<T, 45, 3> dw(datalog, r, n);      // DATALOG / LOG instances only (non-null: the launcher)
+    RowWriter<T, 16> lw(log, r, n);
     VDYN_PHASE_LAP(pc0, 11);     // state loads, engine set-up
     if (!DATALOG && !LOG) {
         // nothing is written per sub-step: between two controller updates the commands are held (drive.py:128), so the
@@ -1021,31 +1115,26 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
         } else {
             eng.template advance_state<true, CS, 0, FS>(P, X, delta, tq, P.mu, h);
         }
-        if (DATALOG && active) {
-            // written once, never read back by this kernel: streaming (non-temporal) stores
-            T *row = datalog + (int64_t)t * 45 * n + r;
-#define VDYN_NT(idx, val) __builtin_nontemporal_store((T)(val), row + (int64_t)(idx) * n)
-            VDYN_NT(0, (T)(phase + t) * h);                                       // drive.py:145
-#pragma unroll
-            for (int i = 0; i < 10; ++i) VDYN_NT(1 + i, X.get(i));                // :146
-#pragma unroll
-            for (int i = 0; i < 10; ++i) VDYN_NT(11 + i, sd[i]);                  // :147
-            VDYN_NT(21, c.delta);                                                 // :148
-#pragma unroll
-            for (int i = 0; i < 4; ++i) VDYN_NT(22 + i, c.tau);                   // :149
-#pragma unroll
-            for (int i = 0; i < 18; ++i) VDYN_NT(26 + i, o18.v[i]);               // :150
-            VDYN_NT(44, c.cte);                                                   // :151
-#undef VDYN_NT
+        if (DATALOG) {
+            // written once, never read back by this kernel: streaming stores through RowWriter
+            const auto row = dw.row();
+            row.template put<0>((T)(phase + t) * h);                              // drive.py:145
+            put_cols<T, 1, 10>(row, [&](int i) { return X.get(i); });             // :146
+            put_cols<T, 11, 10>(row, [&](int i) { return sd[i]; });               // :147
+            row.template put<21>(c.delta);                                        // :148
+            put_cols<T, 22, 4>(row, [&](int) { return c.tau; });                  // :149
+            put_cols<T, 26, 18>(row, [&](int i) { return o18.v[i]; });            // :150
+            row.template put<44>(c.cte);                                          // :151
+            dw.next();
         }
-        if (LOG && log != nullptr && active) {
-            T *row = log + (int64_t)t * 16 * n + r;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) row[(int64_t)i * n] = X.get(i);
-            row[12 * n] = c.delta;
-            row[13 * n] = c.tau;
-            row[14 * n] = (T)c.idx;
-            row[15 * n] = c.cte;
+        if (LOG) {
+            const auto row = lw.row();
+            put_cols<T, 0, 12>(row, [&](int i) { return X.get(i); });
+            row.template put<12>(c.delta);
+            row.template put<13>(c.tau);
+            row.template put<14>((T)c.idx);
+            row.template put<15>(c.cte);
+            lw.next();
         }
     }
     if (active) {

@@ -81,7 +81,9 @@ class AllGatherExchange:
         self._pending = None
 
     def start(self, term_local: torch.Tensor):
-        assert self._pending is None, "wait() for the previous exchange first"
+        # one receive buffer: the previous collective is joined first (for RCCL a stream-level wait: the compute
+        # stream waits, the host does not)
+        self.wait()
         assert tuple(term_local.shape) == (self.rows, self.sh.n_local)
         src = term_local
         if self.send is not None:
@@ -129,12 +131,19 @@ class PeerExchange:
     stream (``vdyn_xchg_*``, include/vdyn.h) -- SDMA / xGMI traffic that leaves the CUs to the next
     rollout.  One process per GPU of ONE node.
 
-    ``start`` orders the copies behind the caller's current stream and returns; ``wait`` blocks the
-    host until THIS rank's copies have landed; a block pushed by another rank is known to have
-    landed once that rank waited and both passed a barrier -- ``result`` and bench.py's fence do
-    exactly that.  UNMEASURED on more than one GPU (none was available to the build); the
-    2-process test on one GPU exercises handles, slots and ordering."""
+    ``start`` orders the copies behind the caller's current stream and returns: the HOST never waits in the steady
+    state.  Exchanges follow each other on the device -- a destination's copies run on one in-order copy stream, so a
+    later block lands after an earlier one -- and the one thing that needs protecting, the SOURCE block until the
+    copies have read it, is protected on the device as well: the last ``DEPTH`` sources stay referenced (so the
+    caching allocator cannot hand their memory to the next rollout), and before the oldest reference is dropped the
+    caller's stream is made to wait for that push's copies (``vdyn_xchg_fence``; by then they finished a whole rollout
+    ago, so the wait never stalls).  A padded send block alternates between two buffers under the same fence.
+    ``wait`` blocks the host until THIS rank's copies have landed; a block pushed by another rank is known to have
+    landed once that rank waited and both passed a barrier -- ``result`` and bench.py's fence do exactly that.
+    UNMEASURED on more than one GPU (none was available to the build); the 2-process test on one GPU exercises
+    handles, slots and ordering."""
 
+    DEPTH = 2           # sources kept alive; < the library's ring of completion events (4)
     kind = "peer_copies"
     fallback_reason = None
 
@@ -163,7 +172,7 @@ class PeerExchange:
                 x.wait()
             except Exception as e:                      # noqa: BLE001 -- any failure means "do not use"
                 ok, why = False, f"self test: pushing to the peers raised {e!r}"
-                x._pending = None
+                x._inflight = []
             if not x._agree(ok):
                 x.close()
                 return None, why or "self test: a rank could not push its block to its peers"
@@ -196,7 +205,7 @@ class PeerExchange:
         self._device = like.device
         self.itemsize = like.element_size()
         self.block, total, self.offsets = slot_layout(sh.world, rows, sh.n_pad, self.itemsize)
-        self._own, self._peers, self._pending, self.recv = None, [], None, None
+        self._own, self._peers, self._inflight, self._count, self.recv, self._closed = None, [], [], 0, None, False
         why = None
         own, ipc = C.c_void_p(), _lib.VdynIpcHandle()
         try:
@@ -206,7 +215,8 @@ class PeerExchange:
             self.recv = torch.as_tensor(_DeviceBuffer(self._own, (sh.world * self.rows, sh.n_pad), typestr),
                                         device=like.device)
             self.recv.zero_()
-            self.send = like.new_zeros((self.rows, sh.n_pad)) if sh.n_local != sh.n_pad else None
+            # a rank holding fewer egos than the largest shard sends a zero-padded block; two of them, alternating
+            self.send = [like.new_zeros((self.rows, sh.n_pad)) for _ in range(self.DEPTH)] if sh.n_local != sh.n_pad else None
             # the zero fill must have RUN before a peer can learn this buffer's handle: its first push could
             # otherwise land before the fill and be wiped by it
             torch.cuda.synchronize(like.device)
@@ -240,41 +250,66 @@ class PeerExchange:
         return self, None
 
     def start(self, term_local: torch.Tensor):
-        assert self._pending is None, "wait() for the previous exchange first"
         assert tuple(term_local.shape) == (self.rows, self.sh.n_local)
+        stream = self._C.c_void_p(torch.cuda.current_stream(term_local.device).cuda_stream)
+        if len(self._inflight) >= self.DEPTH:
+            # the caller's stream waits, on the device, for the copies of the push DEPTH back (lag DEPTH - 1 from the
+            # latest): only then may its source be overwritten (the padded send block below) or freed (the allocator
+            # reuses memory in stream order, and this wait is ahead of anything enqueued from here on)
+            self.h.call("vdyn_xchg_fence", stream, self.DEPTH - 1)
+            self._inflight.pop(0)
         src = term_local.contiguous()
         if self.send is not None:
-            self.send[:, :self.sh.n_local].copy_(term_local)
-            src = self.send
-        stream = self._C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+            src = self.send[self._count % self.DEPTH]
+            src[:, :self.sh.n_local].copy_(term_local)
         self.h.call("vdyn_xchg_push", self._dst, self.sh.world, self.offsets[self.sh.rank],
                     self._C.c_void_p(src.data_ptr()), self.block, stream)
-        self._pending = src                     # stays referenced until the copies have read it
+        self._inflight.append(src)              # stays referenced until the copies have read it
+        self._count += 1
 
     def wait(self):
-        if self._pending is not None:
-            self.h.call("vdyn_xchg_wait")
-            self._pending = None
+        if self._inflight:
+            try:
+                self.h.call("vdyn_xchg_wait")
+            finally:
+                self._inflight = []
 
     def result(self) -> torch.Tensor:
         """[rows][n_units] of the last exchange, a private copy.  Collective: every rank must call it (two barriers).
-        On return no rank reads a slot any more, so any rank may ``start`` the next exchange at once."""
-        self.wait()
+        On return no rank reads a slot any more, so any rank may ``start`` the next exchange at once.  A rank whose
+        own part fails still passes both barriers before it raises: its peers are never left inside one."""
         multi = dist.is_initialized() and self.sh.world > 1
+        err, out = None, None
+        try:
+            self.wait()
+        except Exception as e:                          # noqa: BLE001
+            err = e
         if multi:
             dist.barrier(group=self.sh.group)   # every rank has waited for its own pushes
-        torch.cuda.synchronize(self.recv.device)
-        out = self.sh.assemble(self.recv, self.rows)
-        torch.cuda.synchronize(self.recv.device)   # the copies out of the slots have run ...
+        try:
+            if err is None:
+                torch.cuda.synchronize(self.recv.device)
+                out = self.sh.assemble(self.recv, self.rows)
+                torch.cuda.synchronize(self.recv.device)   # the copies out of the slots have run ...
+        except Exception as e:                          # noqa: BLE001
+            err = e
         if multi:
             dist.barrier(group=self.sh.group)   # ... on every rank, before a faster peer's next push overwrites one
+        if err is not None:
+            raise err
         return out
 
     def close(self):
-        """Collective (a barrier before the buffers go)."""
-        if self._own is None and not self._peers:
+        """Collective (a barrier before the buffers go): EVERY rank passes the barrier, also one that has nothing to
+        free -- the rank whose allocation failed in an agreed-failure path must not skip what its peers enter."""
+        if self._closed:
             return
-        self.wait()
+        self._closed = True
+        err = None
+        try:
+            self.wait()
+        except Exception as e:                          # noqa: BLE001
+            err = e
         if dist.is_initialized() and self.sh.world > 1:
             dist.barrier(group=self.sh.group)   # nobody is still writing into a buffer about to go
         for p in self._peers:
@@ -284,6 +319,8 @@ class PeerExchange:
         if self._own is not None:
             self.h.call("vdyn_xchg_free", self._C.c_void_p(self._own))
         self._own = None
+        if err is not None:
+            raise err
 
 
 def make_exchange(kind: str, sh: ShardedRollout, rows: int, like: torch.Tensor, handle=None):

@@ -346,15 +346,16 @@ class VehicleModel:
         term = be.out(rows, n)
         traj = be.out(H // traj_stride, 12, n) if traj_stride > 0 else None
         h = self._handle(be.device_index(self.device), p)
-        if rows != 12:
-            h.call("vdyn_set_option", _lib.VDYN_OPT_STATE_ROWS, rows)
-        try:
-            h.call(f"vdyn_rollout_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(ct), int(k), layout,
-                   _vp(pid), int(P), float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj),
-                   int(traj_stride), *be.stream_args())
-        finally:
+        with h.lock:        # the row count is handle state: set, launch and reset as one step (see _lib.Handle.lock)
             if rows != 12:
-                h.call("vdyn_set_option", _lib.VDYN_OPT_STATE_ROWS, 12)
+                h.call("vdyn_set_option", _lib.VDYN_OPT_STATE_ROWS, rows)
+            try:
+                h.call(f"vdyn_rollout_{be.suffix}_{be.kind}", n, int(H), _vp(s0), _vp(ct), int(k), layout,
+                       _vp(pid), int(P), float(self.dt if dt is None else dt), mu4, _vp(term), _vp(traj),
+                       int(traj_stride), *be.stream_args())
+            finally:
+                if rows != 12:
+                    h.call("vdyn_set_option", _lib.VDYN_OPT_STATE_ROWS, 12)
         del keep
         return (term, traj) if traj_stride > 0 else term
 

@@ -35,6 +35,9 @@ class OracleCompute:
             t[3, t.shape[1] // 2] = np.nextafter(t[3, t.shape[1] // 2], np.float32(np.inf))
         return torch.from_numpy(t)
 
+    def with_lanes(self, lanes_per_rollout):
+        return self         # the oracle has one mapping; bench.py's `strong` section only needs the object
+
     def handle(self):
         return None
 

@@ -27,12 +27,19 @@ if __name__ == "__main__":
     pidd = torch.from_numpy(pid[sh.lo:sh.hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
     x = D.make_exchange("p2p", sh, 12, s0d, handle=vm.handle())
-    full = None
-    for it in range(3):                                               # three steps: slots are rewritten in place
-        term = vm.rollout(s0d, tabd, path_id=pidd)
-        x.wait()
-        x.start(term)
+    # Four exchanges back to back, no host wait in between (the steady state of bench.py's step): three blocks of
+    # distinct constants, then the real terminal states.  Pushes follow each other on the device, so the LAST one
+    # wins in every slot of every rank; the sources of the earlier ones are released behind a device-side fence.
+    term = vm.rollout(s0d, tabd, path_id=pidd)
+    for it in range(3):
+        x.start(torch.full_like(term, float(100 * (rank + 1) + it)))
+    x.start(term)
     full = x.result()
+    # ... and once more after a result(): slots are rewritten in place, the host-side wait has reset the ring
+    x.start(torch.full_like(term, -1.0))
+    x.start(vm.rollout(s0d, tabd, path_id=pidd))
+    again = x.result()
+    assert torch.equal(again, full), "the second round of exchanges must deliver the same blocks"
     np.save(os.path.join(out_dir, f"p2p_rank{rank}.npy"), full.cpu().numpy())
     x.close()
     dist.barrier()

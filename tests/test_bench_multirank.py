@@ -14,9 +14,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRY = os.path.join(REPO, "tests", "_bench_gloo_entry.py")
 
 
-def _launch(tmp_path, world, extra, env_extra=None):
+def _launch(tmp_path, world, extra, env_extra=None, cpu_baseline=False):
     argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-extra",
-            "--no-cpu-baseline", "--horizon", "12", "--dump-gathered", str(tmp_path), *extra]
+            "--horizon", "12", "--dump-gathered", str(tmp_path), *extra]
+    if not cpu_baseline:
+        argv.append("--no-cpu-baseline")
     code = ("import sys; sys.path.insert(0, %r); import bench; "
             "sys.exit(bench.spawn_ranks(%d, %r, script=%r))" % (REPO, world, argv, ENTRY))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
@@ -46,6 +48,19 @@ def test_bench_two_ranks_shard_by_whole_egos_and_gather_bitwise(tmp_path, mode, 
     assert out["value"] > 0 and out["steps"] == 2 and out["unit"] == "vehicle-steps/s"
     if mode == "weak":
         assert n_total == world * (per_gpu // 7) * 7 and len({hi - lo for lo, hi in shards}) == 1
+    # the default N > 1 line is complete: both exchanges side by side, the fixed-N split
+    # with both kernels, per-GPU rooflines -- all outside the timed region, all verified
+    ab = out["exchange_ab"]
+    assert ab["steps"] == 1 and ab["rccl"]["available"] and ab["rccl"]["verified"] is True and ab["rccl"]["ms_per_step"] > 0
+    assert ab["rccl"]["kind"] == "all_gather_into_tensor"
+    assert ab["p2p"]["available"] is False and "handle" in ab["p2p"]["reason"]     # CPU stand-in: no library handle
+    st = out["strong"]
+    assert st["rollouts_total"] == per_gpu and "error" not in st
+    assert st["shards"] == [list(workloads.shard_egos(per_gpu, world, r)) for r in range(world)]
+    for k, ln in (("lane", 1), ("wheel_parallel", 4)):
+        assert st[k]["verified"] is True and st[k]["ms_per_step"] > 0 and st[k]["lanes_per_rollout"] == ln
+    assert out["roofline_hbm"]["frac"] > 0 and out["roofline_hbm"]["per_gpu"] is True and out["roofline"]["per_gpu"] is True
+    assert "sections_timed_out" not in out and "_section" not in out
     # what every rank holds after the last exchange == the single-process result, bit for bit
     s0, tab, pid = workloads.config3(n_total, 12, np.float32)
     single = oracle.rollout(oracle.default_params(), s0.astype(np.float64), tab.astype(np.float64), 1e-3,
@@ -61,6 +76,21 @@ def test_one_ulp_of_difference_in_a_peer_block_is_reported_as_unverified(tmp_pat
     the verdict rank 0 prints is the AND over the ranks."""
     out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70"], env_extra={"VDYN_TEST_FLIP_RANK": "1"})
     assert out["exchange"]["verified"] is False and "bitwise" in out["exchange"]["verified_how"]
+
+
+def test_default_multirank_line_carries_the_cpu_baseline(tmp_path):
+    """N > 1 without --no-cpu-baseline: rank 0 times the oracle on its host while the other ranks wait at the closing
+    barrier; the line carries `cpu_baseline` as at N = 1 (no fp32 state error here: not the full-size workload)."""
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70"], cpu_baseline=True)
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    assert out["gpu_over_cpu"] > 0 and "fp32_state_error" not in out
+    assert out["exchange_ab"]["rccl"]["verified"] is True and out["strong"]["lane"]["verified"] is True
+
+
+def test_sections_can_be_switched_off(tmp_path):
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--no-sections"])
+    assert "exchange_ab" not in out and "strong" not in out and out["exchange"]["verified"] is True
 
 
 def test_total_rollouts_keeps_one_wave_per_simd():

@@ -101,3 +101,75 @@ def test_peer_exchange_slot_arithmetic(pkg):
     full = sh.assemble(flat.view(3 * 12, 28), 12)
     want = torch.arange(65, dtype=torch.float32)[None, :] + 1000.0 * torch.arange(12)[:, None]
     assert torch.equal(full, want)
+
+
+class _MockXchgHandle:
+    """Stands in for the library handle in PeerExchange's set-up: `vdyn_xchg_alloc` hands out host memory (or raises,
+    on the rank told to fail), the other entry points record that they were called."""
+
+    def __init__(self, fail_alloc):
+        self.fail_alloc, self.calls, self.buf = fail_alloc, [], None
+
+    def call(self, name, *args):
+        import ctypes as C
+        self.calls.append(name)
+        if name == "vdyn_xchg_alloc":
+            if self.fail_alloc:
+                raise RuntimeError("mock: hipMalloc failed on this rank")
+            total, own_ref = args[0], args[1]
+            self.buf = (C.c_char * int(total))()
+            own_ref._obj.value = C.addressof(self.buf)
+        elif name == "vdyn_xchg_open":
+            raise RuntimeError("mock: no peer mapping on the CPU")
+
+
+def _peer_failure_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import ctypes as C
+    import importlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        importlib.import_module("python-motionplanning_amd")
+        D = importlib.import_module("python-motionplanning_amd.distributed")
+
+        def host_buffer(ptr, shape, typestr):       # the slot buffer as a NumPy view of the mock's host memory
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array((C.c_float * n).from_address(int(ptr))).reshape(shape)
+        D._DeviceBuffer = host_buffer
+        torch.cuda.synchronize = lambda *a, **k: None
+        sh = D.ShardedRollout(70)
+        like = torch.zeros((12, sh.n_local), dtype=torch.float32)
+        h = _MockXchgHandle(fail_alloc=(rank == 1))
+        x, why = D.PeerExchange.try_create(sh, 12, like, h)
+        assert x is None and why, (x, why)
+        # the very next collective of the `auto` fallback: must pair up on every rank (the rank that had nothing to
+        # free used to skip close()'s barrier, and its peers' barrier then met THIS all-gather)
+        fb = D.make_exchange("rccl", sh, 12, like)
+        fb.start(torch.full((12, sh.n_local), float(rank + 1)))
+        got = fb.result()
+        for r, (lo, hi) in enumerate(sh.bounds):
+            assert bool((got[:, lo:hi] == float(r + 1)).all())
+        with open(os.path.join(out_dir, f"peer_failure_{rank}.txt"), "w") as f:
+            f.write(why + "\n" + ",".join(h.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_one_rank_cannot_allocate_all_ranks_fall_back_together(tmp_path):
+    """PeerExchange.close() is collective, also for the rank that holds nothing.  Rank 1's
+    vdyn_xchg_alloc raises; both ranks must get (None, reason) from try_create and then complete an all-gather."""
+    world = 2
+    ctx = mp.spawn(_peer_failure_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > 120:
+            for pr in ctx.processes:
+                pr.kill()
+            pytest.fail("the ranks did not come back: a barrier met another collective")
+    why0 = (tmp_path / "peer_failure_0.txt").read_text()
+    why1 = (tmp_path / "peer_failure_1.txt").read_text()
+    assert "could not export" in why0 or "another rank" in why0
+    assert "rank 1" in why1 and "mock: hipMalloc failed" in why1
+    assert "vdyn_xchg_free" in why0.splitlines()[1], "the healthy rank frees what it allocated"

@@ -162,3 +162,14 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
                                "requested": exchange, "fallback_reason": None}
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
     assert out["roofline"]["bound"] == "valu" and out["shards"] == [[0, 65536]]
+    # the sections an 8-GPU run adds to its one line: RCCL and peer copies side by side, the fixed-65536 split with both
+    # kernels -- each verified -- and the per-GPU HBM roofline
+    ab, st = out["exchange_ab"], out["strong"]
+    for kind, name in (("rccl", "all_gather_into_tensor"), ("p2p", "peer_copies")):
+        assert ab[kind]["available"] and ab[kind]["kind"] == name and ab[kind]["verified"] is True, ab
+        assert 0 < ab[kind]["ms_per_step"] < 5.0
+    assert st["rollouts_total"] == 65536 and st["shards"] == [[0, 65536]] and "error" not in st
+    assert st["lane"]["verified"] is True and st["wheel_parallel"]["verified"] is True
+    assert st["lane"]["lanes_per_rollout"] == 1 and st["wheel_parallel"]["lanes_per_rollout"] == 4
+    assert 0 < out["roofline_hbm"]["frac"] < 1 and out["roofline_hbm"]["per_gpu"] is True
+    assert "sections_timed_out" not in out

@@ -20,6 +20,9 @@ class OracleBackedHandle:
         self.p = oracle.default_params()
         self.calls = []
         self.param_sets = 0
+        import threading
+        self.lock = threading.RLock()           # what _lib.Handle carries (set_option / launch / reset as one step)
+        self.rows_seen = []                     # (rows the option said at launch, rows of the caller's state)
 
     def set_params(self, cp, key=None):
         self.param_sets += 1
@@ -60,11 +63,14 @@ class OracleBackedHandle:
                 _view(term, 12 * n)[:] = out.ravel()
         elif name == "vdyn_set_option":
             self.options = getattr(self, "options", []) + [tuple(a)]
+            import time
+            time.sleep(0)                       # invite a thread switch between "set" and "launch"
         elif name == "vdyn_rollout_f32_host":
             # records the marshalling only: rows of the state arrays follow the option set just before
             n, H, s0, ct, k, layout, pid, P, dt, mu4, term, traj, stride = a
             self.rollout_rows = [v for o, v in self.options if o == 2][-1] if getattr(self, "options", None) else 12
             rows = self.rollout_rows
+            self.rows_seen.append((rows, getattr(self, "caller_rows", {}).get(n)))
             src = np.ctypeslib.as_array((C.c_float * (rows * n)).from_address(s0.value)).reshape(rows, n)
             np.ctypeslib.as_array((C.c_float * (rows * n)).from_address(term.value)).reshape(rows, n)[:] = src + 1.0
         else:
@@ -206,3 +212,32 @@ def test_dropin_warns_like_numpy_on_nonfinite_results(vm_mock, pkg):
         warnings.simplefilter("always")
         vm.planar_model_RK4([25.0, 0, 0] + [25.0 / p.rw] * 4 + [0, 0, 0], [0.0] * 4, [1.0] * 4, [0.0] * 4, p, 0.0, 0.0)
     assert not [x for x in w if "planar_model_RK4" in str(x.message)]
+
+
+def test_state_rows_option_is_not_shared_between_threads(vm_mock, workloads):
+    """VDYN_OPT_STATE_ROWS is handle state; two threads on one VehicleModel -- one with [12][N], one
+    with [22][N] states -- must each launch with their own row count (a 12-row call launched while the option says 22
+    reads and writes 22 rows of 12-row buffers)."""
+    import threading
+    vm, h = vm_mock
+    n12, n22 = 14, 21                                       # the batch size tells the mock whose call it is
+    h.caller_rows = {n12: 12, n22: 22}
+    _, tab, _ = workloads.config3(7, 5, np.float32)
+    pid12, pid22 = (np.arange(n12) % 7).astype(np.int32), (np.arange(n22) % 7).astype(np.int32)
+    s12 = np.zeros((12, n12), np.float32)
+    s22 = np.zeros((22, n22), np.float32)
+    errs = []
+
+    def work(s, pid):
+        try:
+            for _ in range(150):
+                out = vm.rollout(s, tab, path_id=pid)
+                assert out.shape == s.shape
+        except Exception as e:                              # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=a) for a in ((s12, pid12), (s22, pid22))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert len(h.rows_seen) == 300 and all(opt == mine for opt, mine in h.rows_seen), \
+        [x for x in h.rows_seen if x[0] != x[1]][:5]
