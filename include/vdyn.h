@@ -254,9 +254,9 @@ int vdyn_mpc_argmin_f64_host(VdynHandle *h, int32_t E, int32_t C, int32_t H, con
  * (the held commands, drive.py:138,131).  Waypoints: wp [P][Wmax][2] = (x, y) rows of the
  * lists LateralTrackerObj.update_waypoints receives (local_planner.py:419), wcount [P] valid
  * rows per table, path_id [n] the table each vehicle tracks.  fp32: the lookahead walk runs on the
- * cumulative arc length of a table, so the first wcount rows of an fp32 table must be finite (a NaN
- * row would poison the sums behind it; the reference -- and the fp64 entry points -- only meet such
- * a row when the walk crosses it).                                                            */
+ * cumulative arc length of a table; a table with a non-finite row (which poisons the sums behind
+ * it) is walked segment by segment instead, as the reference -- and the fp64 entry points -- walk
+ * every table: a non-finite row only matters when the walk crosses it.                        */
 
 /* Gains of Car.__init__ (drive.py:56,71-85): k=100, k_soft=1, max_steer=30 deg, lookahead=5,
  * deadband=0.01 (stanley_controller.py:46-47), kp=1000, ki=100, kd=0, filter 1e-5/(2*0.001). */
@@ -505,7 +505,9 @@ int vdyn_xchg_close(VdynHandle *h, void *peer_ptr);
  * follow each other on the device (destination i always uses the same in-order copy stream, so of
  * two pushes into the same slot the later one lands last).  What the CALLER must keep is the source
  * block, until the push's copies have read it: vdyn_xchg_fence orders its reuse on the device.
- * On an error, copies already queued have been waited for before the call returns.             */
+ * On an error, copies already queued have been waited for before the call returns.  The copies are
+ * asked to run on the DMA engines (hipMemcpyDeviceToDeviceNoCU): a blit kernel would share the SIMDs
+ * with the next rollout's one wave each; a runtime that refuses that kind gets plain copies.        */
 int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
                    uint64_t bytes, void *after_stream);
 /* Make `stream` wait -- on the device; the host does not block -- until the copies of the push issued

@@ -975,6 +975,31 @@ __device__ __forceinline__ void stanley_control(const CtrlGains<T> &G, const WP 
             // cum[last] < target (the path ends before the lookahead distance): the reference stops at the last waypoint
             ce = hi;
         }
+        // A non-finite waypoint poisons the cumulative arc from there to the table's end: the search above then
+        // answers best_i + 1 (every comparison with a NaN fails), where the reference -- which adds the segments one by
+        // one from the nearest waypoint (:68-76) -- walks on normally when the bad row lies BEHIND the vehicle and runs
+        // to the last waypoint when the walk crosses it (a NaN total is never >= the lookahead).  Such a table is
+        // known by its end, cum[last], which the lane holds as `per`: its vehicles take the reference's walk, on the
+        // coordinates themselves.  No lane does on a finite table: one compare and a branch never taken.
+        const T per_ = WP::kSoa ? wp.per : (T)last / wp.seg_at(last);
+        const bool poisoned = !(per_ == per_) || per_ == T(0);       // cum[last] NaN / inf
+        if (__builtin_expect(__any(poisoned) != 0, 0)) {
+            if (poisoned) {
+                T tot = total, ax_, ay_;
+                int c2 = best_i;
+                wp.get(best_i, ax_, ay_);
+                for (int i = best_i + 1; i < wp.W; ++i) {
+                    if (tot >= G.lookahead) break;
+                    T qx, qy;
+                    wp.get(i, qx, qy);
+                    tot += segment_length<T>(ax_, ay_, qx, qy);
+                    c2 = i;
+                    ax_ = qx;
+                    ay_ = qy;
+                }
+                ce = c2;
+            }
+        }
         wp.get(ce, px, py);
     } else if (wp.seg != nullptr) {
         // same sequential sum as the reference, sixteen precomputed segment lengths per trip.  The

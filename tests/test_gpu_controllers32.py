@@ -231,11 +231,11 @@ def test_closed_loop_search_on_adversarial_tables(gpu_vm, pkg, oracle):
     big[:, :203] = wp
     t2, c2 = vm.closed_loop(s0, c0, big, H, wcount=wc, path_id=pid)
     assert np.array_equal(t2[:, ok], term[:, ok]) and np.array_equal(c2[:, ok], cs[:, ok])
-    # fp32: same tables (203 floats per row: the scalar staging path).  Two things are the precision's, not the
-    # search's: a vehicle AT the figure-eight's crossing takes either branch (the plain-C float oracle differs from the
-    # fp64 one on 12 % of that table's updates), so fp32 is held to the FLOAT oracle; and the fp32 lookahead works on
-    # the cumulative arc length, which a NaN waypoint poisons for everything behind it (the reference -- and the fp64
-    # path -- only meet a NaN segment when the walk crosses it): fp32 tables must be finite up to wcount (include/vdyn.h).
+    # fp32: same tables (203 floats per row: the scalar staging path).  A vehicle AT the figure-eight's crossing takes
+    # either branch (the plain-C float oracle differs from the fp64 one on 12 % of that table's updates), so fp32 is held
+    # to the FLOAT oracle.  The NaN-waypoint table is part of the comparison: the fp32 lookahead works on the cumulative
+    # arc length, which a NaN waypoint poisons for everything behind it -- such a table is walked segment by segment, as
+    # the reference walks every table (round 3 excluded the table and asked callers for finite fp32 tables instead).
     with np.errstate(all="ignore"):
         _, _, olog32 = oracle.closed_loop(oracle.default_params(), cp, s0.astype(np.float32), c0.astype(np.float32),
                                           wp.astype(np.float32), wc, pid, dt, H, log=True, nthreads=8)
@@ -248,7 +248,10 @@ def test_closed_loop_search_on_adversarial_tables(gpu_vm, pkg, oracle):
     assert np.isfinite(idx4).all() and (idx4 >= 0).all() and (idx4 < wc[4]).all(), "fp32 target index out of the NaN table's range"
     assert np.isfinite(log32[:, 12][:, t4]).all() and np.abs(log32[:, 12][:, t4]).max() <= np.deg2rad(30) + 1e-6
     assert np.isfinite(t32[:, t4]).all() and np.isfinite(c32[:, t4]).all(), "fp32 state on the NaN table must stay finite"
-    ok32 = ok & np.isfinite(t32).all(axis=0) & (pid != 4)
+    ok32 = ok & np.isfinite(t32).all(axis=0)
+    off4 = (np.abs(log32[::10, 14][:, t4] - olog32[::10, 14][:, t4]) > 1).mean()
+    print(f"\n  NaN-waypoint table, fp32: finite, in range, indices more than one off the float oracle's on {off4:.2%}")
+    assert off4 <= 0.02
     didx = np.abs(log32[::10, 14][:, ok32] - olog32[::10, 14][:, ok32])
     off = (didx > 1).mean()
     print(f"\n  adversarial tables: {ok.mean():.1%} finite in the oracle, fp32 indices more than one off the float oracle's on {off:.2%}")

@@ -4,11 +4,11 @@
 # the `nccl` backend, one rank, one GPU (--force-collective).  Each run is a fresh process.
 # Usage (repo root, via gpurun):  bash tools/exchange_one_rank.sh <tag>   ->  gpurun_out/<tag>_exchange_one_rank.json
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
-COMMON="--no-extra --no-cpu-baseline"
+COMMON="--no-extra --no-cpu-baseline --no-sections"
 run() {   # name, extra flags
   local name=$1; shift
   timeout -k 10 300 python3 "$ROOT/bench.py" $COMMON "$@" > "$OUT/xchg_$name.json" 2> "$OUT/xchg_$name.err"
