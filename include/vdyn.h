@@ -505,13 +505,11 @@ int vdyn_xchg_close(VdynHandle *h, void *peer_ptr);
  * follow each other on the device (destination i always uses the same in-order copy stream, so of
  * two pushes into the same slot the later one lands last).  What the CALLER must keep is the source
  * block, until the push's copies have read it: vdyn_xchg_fence orders its reuse on the device.
- * On an error, copies already queued have been waited for before the call returns.  The copies are
- * asked to run on the DMA engines (hipMemcpyDeviceToDeviceNoCU): a blit kernel would share the SIMDs
- * with the next rollout's one wave each; a runtime that refuses that kind gets plain copies.        */
+ * On an error, copies already queued have been waited for before the call returns.             */
 int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
                    uint64_t bytes, void *after_stream);
 /* Make `stream` wait -- on the device; the host does not block -- until the copies of the push issued
- * `lag` pushes before the latest one have finished (lag 0: the latest push; 0 <= lag < 4).  After
+ * `lag` pushes before the latest one have finished (lag 0: the latest push; 0 <= lag < 8).  After
  * it, work enqueued on `stream` may overwrite (or the allocator may hand out) that push's source.
  * A no-op when no such push exists.                                                             */
 int vdyn_xchg_fence(VdynHandle *h, void *stream, int32_t lag);

@@ -32,12 +32,11 @@ struct VdynHandle {
     // (round robin beyond kCopyStreams), so that the copies to different peers can use different SDMA engines and
     // xGMI links at the same time instead of queueing behind each other
     static constexpr int kCopyStreams = 8;
-    static constexpr int kPushRing = 4;     // pushes whose completion events are kept (vdyn_xchg_fence looks back this far)
+    static constexpr int kPushRing = 8;     // pushes whose completion events are kept (vdyn_xchg_fence looks back this far)
     hipStream_t copy_stream[kCopyStreams] = {};
     hipEvent_t ev_ready = nullptr, ev_done[kPushRing][kCopyStreams] = {};
     int push_streams = 0;           // copy streams in use (0: no push issued since the last vdyn_xchg_wait)
     int64_t pushes = 0;             // pushes issued over the handle's life; push k records ev_done[k % kPushRing]
-    bool copy_no_cu = true;         // peer copies ask for the DMA engines (hipMemcpyDeviceToDeviceNoCU) until one is refused
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -291,23 +290,11 @@ int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_
         e = hipStreamWaitEvent(h->copy_stream[i], h->ev_ready, 0);                   // ... before any copy reads it
     int queued = 0;
     for (int i = 0; i < n_dst && e == hipSuccess; ++i) {
-        // "without using compute units": the copy must not become a blit KERNEL -- every SIMD already holds the one
-        // wave of the next rollout, and a second resident wave costs it issue slots (what the RCCL all-gather's copy
-        // kernel costs: +8 % per step with one rank, profiles/r04_exchange_one_rank.json).  A runtime that refuses
-        // the kind gets the plain device-to-device copy from then on.
-        char *to = static_cast<char *>(dst[i]) + dst_offset;
-        if (h->copy_no_cu) {
-            e = hipMemcpyAsync(to, src, bytes, hipMemcpyDeviceToDeviceNoCU, h->copy_stream[i % ns]);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                h->copy_no_cu = false;
-                e = hipSuccess;
-            } else {
-                ++queued;
-                continue;
-            }
-        }
-        e = hipMemcpyAsync(to, src, bytes, hipMemcpyDeviceToDevice, h->copy_stream[i % ns]);
+        // plain device-to-device copies: to a PEER device the runtime takes the DMA engines over xGMI by itself.
+        // Asking for them explicitly (hipMemcpyDeviceToDeviceNoCU) was measured and dropped: on ROCm 7.2 that call blocks
+        // the HOST until the copy has run (0.22 ms per step instead of 0.03: profiles/README.md, round 4 log)
+        e = hipMemcpyAsync(static_cast<char *>(dst[i]) + dst_offset, src, bytes, hipMemcpyDeviceToDevice,
+                           h->copy_stream[i % ns]);
         if (e == hipSuccess) ++queued;
     }
     for (int i = 0; i < ns && e == hipSuccess; ++i) e = hipEventRecord(done[i], h->copy_stream[i]);

@@ -650,6 +650,9 @@ __device__ __forceinline__ void nearest_in_subblocks(const WP &wp, int sb0, unsi
     const T inf = T(INFINITY);
     T best = inf, second = inf;
     int best_sb = -1;
+    T dw[8];                                                          // the eight distances of the sub-block that holds `best`
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dw[k] = inf;
     // two sub-blocks per trip (their sixteen distances are independent work for a lone wave; half the loop overhead)
     while (__any(mask != 0u)) {
         const bool act0 = mask != 0u;
@@ -676,19 +679,20 @@ __device__ __forceinline__ void nearest_in_subblocks(const WP &wp, int sb0, unsi
         second = min_t(better ? best : min_t(second, m), other);
         best = better ? m : best;
         best_sb = better ? sbm : best_sb;
+        // the winner's eight distances stay in registers (two selects each per trip; a lane makes one or two trips):
+        // the resolve below used to re-read the winning sub-block and recompute them -- four LDS reads, thirty-two
+        // instructions and a round trip on the update's critical path
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dw[k] = better ? (b_wins ? db[k] : da[k]) : dw[k];
     }
     // the winner inside its sub-block: the first of the eight that equals the minimum
     const int sbr = best_sb < 0 ? sb0 : best_sb;
-    Block8<T> win;
-    win.load(wp.base, wp.yo, sbr * kSubBlock);
-    T d2[8];
-    win.d2(x, y, d2);
     const T thr = best * (T(2) - L::kTieBand);                        // 1 + 16 ulp
     int k_first = 0, close = 0;
 #pragma unroll
     for (int k = 7; k >= 0; --k) {
-        k_first = d2[k] == best ? k : k_first;
-        close += d2[k] <= thr ? 1 : 0;
+        k_first = dw[k] == best ? k : k_first;
+        close += dw[k] <= thr ? 1 : 0;
     }
     best_d2 = best;
     best_i = best_sb < 0 ? 0 : sbr * kSubBlock + k_first;            // nothing comparable: the scan's initial 0

@@ -134,16 +134,18 @@ class PeerExchange:
     ``start`` orders the copies behind the caller's current stream and returns: the HOST never waits in the steady
     state.  Exchanges follow each other on the device -- a destination's copies run on one in-order copy stream, so a
     later block lands after an earlier one -- and the one thing that needs protecting, the SOURCE block until the
-    copies have read it, is protected on the device as well: the last ``DEPTH`` sources stay referenced (so the
-    caching allocator cannot hand their memory to the next rollout), and before the oldest reference is dropped the
-    caller's stream is made to wait for that push's copies (``vdyn_xchg_fence``; by then they finished a whole rollout
-    ago, so the wait never stalls).  A padded send block alternates between two buffers under the same fence.
+    copies have read it, is protected on the device as well: the last ``2 * HOLD`` sources stay referenced (so the
+    caching allocator cannot hand their memory to the next rollout), and every ``HOLD`` exchanges ONE device-side wait
+    (``vdyn_xchg_fence``: the caller's stream waits for the copies of the push ``HOLD`` back, which finished several
+    rollouts ago) releases the ``HOLD`` oldest -- a stream-wait is a barrier packet between two kernels, so it is paid
+    once per ``HOLD`` steps, not per step.  A padded send block rotates through ``2 * HOLD`` buffers under the same
+    fence.  A rank's OWN block is not copied per step at all: ``result`` places the last one in its slot.
     ``wait`` blocks the host until THIS rank's copies have landed; a block pushed by another rank is known to have
     landed once that rank waited and both passed a barrier -- ``result`` and bench.py's fence do exactly that.
-    UNMEASURED on more than one GPU (none was available to the build); the 2-process test on one GPU exercises
-    handles, slots and ordering."""
+    UNMEASURED on more than one GPU (none was available to the build); the 2- and 4-process rehearsals on one GPU
+    exercise handles, slots and ordering."""
 
-    DEPTH = 2           # sources kept alive; < the library's ring of completion events (4)
+    HOLD = 4            # 2 * HOLD sources kept alive = the library's ring of completion events (8)
     kind = "peer_copies"
     fallback_reason = None
 
@@ -206,6 +208,7 @@ class PeerExchange:
         self.itemsize = like.element_size()
         self.block, total, self.offsets = slot_layout(sh.world, rows, sh.n_pad, self.itemsize)
         self._own, self._peers, self._inflight, self._count, self.recv, self._closed = None, [], [], 0, None, False
+        self._last = None
         why = None
         own, ipc = C.c_void_p(), _lib.VdynIpcHandle()
         try:
@@ -216,7 +219,7 @@ class PeerExchange:
                                         device=like.device)
             self.recv.zero_()
             # a rank holding fewer egos than the largest shard sends a zero-padded block; two of them, alternating
-            self.send = [like.new_zeros((self.rows, sh.n_pad)) for _ in range(self.DEPTH)] if sh.n_local != sh.n_pad else None
+            self.send = [like.new_zeros((self.rows, sh.n_pad)) for _ in range(2 * self.HOLD)] if sh.n_local != sh.n_pad else None
             # the zero fill must have RUN before a peer can learn this buffer's handle: its first push could
             # otherwise land before the fill and be wiped by it
             torch.cuda.synchronize(like.device)
@@ -243,7 +246,9 @@ class PeerExchange:
                     ptrs[r] = peer.value
             except Exception as e:                      # noqa: BLE001
                 why = f"rank {sh.rank}: opening a peer's slot buffer failed: {e!r}"
-        self._dst = ptrs
+        # destinations of a push: every rank's buffer but this rank's own (its block is placed by result())
+        others = [ptrs[r] for r in range(sh.world) if r != sh.rank]
+        self._dst, self._n_dst = (C.c_void_p * max(len(others), 1))(*others), len(others)
         if not self._agree(why is None):
             self.close()
             return None, why or "another rank could not set up its peer buffers"
@@ -252,19 +257,21 @@ class PeerExchange:
     def start(self, term_local: torch.Tensor):
         assert tuple(term_local.shape) == (self.rows, self.sh.n_local)
         stream = self._C.c_void_p(torch.cuda.current_stream(term_local.device).cuda_stream)
-        if len(self._inflight) >= self.DEPTH:
-            # the caller's stream waits, on the device, for the copies of the push DEPTH back (lag DEPTH - 1 from the
-            # latest): only then may its source be overwritten (the padded send block below) or freed (the allocator
-            # reuses memory in stream order, and this wait is ahead of anything enqueued from here on)
-            self.h.call("vdyn_xchg_fence", stream, self.DEPTH - 1)
-            self._inflight.pop(0)
+        if len(self._inflight) >= 2 * self.HOLD:
+            # the caller's stream waits, on the device, for the copies of the push HOLD back from the latest: that and
+            # everything older has then been read, so the HOLD oldest sources may be overwritten (the padded send
+            # blocks below) or freed (the allocator reuses memory in stream order, and this wait is ahead of anything
+            # enqueued from here on)
+            self.h.call("vdyn_xchg_fence", stream, self.HOLD)
+            del self._inflight[:self.HOLD]
         src = term_local.contiguous()
         if self.send is not None:
-            src = self.send[self._count % self.DEPTH]
+            src = self.send[self._count % (2 * self.HOLD)]
             src[:, :self.sh.n_local].copy_(term_local)
-        self.h.call("vdyn_xchg_push", self._dst, self.sh.world, self.offsets[self.sh.rank],
+        self.h.call("vdyn_xchg_push", self._dst, self._n_dst, self.offsets[self.sh.rank],
                     self._C.c_void_p(src.data_ptr()), self.block, stream)
         self._inflight.append(src)              # stays referenced until the copies have read it
+        self._last = src
         self._count += 1
 
     def wait(self):
@@ -289,6 +296,9 @@ class PeerExchange:
         try:
             if err is None:
                 torch.cuda.synchronize(self.recv.device)
+                if self._last is not None:      # this rank's own block: never sent anywhere, placed here
+                    own = self.recv.view(self.sh.world, self.rows, self.sh.n_pad)[self.sh.rank]
+                    own[:, :self._last.shape[1]].copy_(self._last)
                 out = self.sh.assemble(self.recv, self.rows)
                 torch.cuda.synchronize(self.recv.device)   # the copies out of the slots have run ...
         except Exception as e:                          # noqa: BLE001
