@@ -453,7 +453,7 @@ int vdyn_nonfinite_lanes_f32_host(VdynHandle *h, int32_t rows, int64_t n, const 
  * all four wheels pass and every B >= 0, and keep the atan -> sine chain otherwise -- or VDYN_ERR_ARG
  * (coef is still filled in). */
 int vdyn_tire_fit_f32(double C, float *coef);
-/* The same for the fp64 step: coef [19], degree 18, checked to 4e-15.  The fp64 kernels carry ONE set of
+/* The same for the fp64 step: coef [17], degree 16, checked to 5e-14 (2.3e-14 for the reference's C).  The fp64 kernels carry ONE set of
  * coefficients: a handle uses the fit only if its four wheels share C (the reference's parameters do,
  * vehicle_model.py:44-45). */
 int vdyn_tire_fit_f64(double C, double *coef);
@@ -508,11 +508,12 @@ int vdyn_xchg_close(VdynHandle *h, void *peer_ptr);
  * On an error, copies already queued have been waited for before the call returns.             */
 int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_offset, const void *src,
                    uint64_t bytes, void *after_stream);
-/* Make `stream` wait -- on the device; the host does not block -- until the copies of the push issued
- * `lag` pushes before the latest one have finished (lag 0: the latest push; 0 <= lag < 8).  After
- * it, work enqueued on `stream` may overwrite (or the allocator may hand out) that push's source.
- * A no-op when no such push exists.                                                             */
-int vdyn_xchg_fence(VdynHandle *h, void *stream, int32_t lag);
+/* Make `stream` wait -- on the device; the host does not block -- until every push issued so far has
+ * finished.  After it, work enqueued on `stream` may overwrite (or the allocator may hand out) the
+ * sources of those pushes.  Call it once per several pushes, while keeping the sources of the pushes
+ * since the previous fence alive (distributed.PeerExchange: every fourth): a stream-wait is a
+ * barrier between two kernels.  A no-op when nothing was pushed.                                  */
+int vdyn_xchg_fence(VdynHandle *h, void *stream);
 /* Block the host until all of this handle's pushes have landed (a no-op when none is in flight). */
 int vdyn_xchg_wait(VdynHandle *h);
 

@@ -126,7 +126,7 @@ SIGNATURES.update({
     "vdyn_xchg_open": (_int, [_vp, C.POINTER(VdynIpcHandle), C.POINTER(_vp)]),
     "vdyn_xchg_close": (_int, [_vp, _vp]),
     "vdyn_xchg_push": (_int, [_vp, C.POINTER(_vp), _i32, _u64, _vp, _u64, _vp]),
-    "vdyn_xchg_fence": (_int, [_vp, _vp, _i32]),
+    "vdyn_xchg_fence": (_int, [_vp, _vp]),
     "vdyn_xchg_wait": (_int, [_vp]),
 })
 

@@ -32,11 +32,9 @@ struct VdynHandle {
     // (round robin beyond kCopyStreams), so that the copies to different peers can use different SDMA engines and
     // xGMI links at the same time instead of queueing behind each other
     static constexpr int kCopyStreams = 8;
-    static constexpr int kPushRing = 8;     // pushes whose completion events are kept (vdyn_xchg_fence looks back this far)
     hipStream_t copy_stream[kCopyStreams] = {};
-    hipEvent_t ev_ready = nullptr, ev_done[kPushRing][kCopyStreams] = {};
+    hipEvent_t ev_ready = nullptr, ev_done[kCopyStreams] = {};
     int push_streams = 0;           // copy streams in use (0: no push issued since the last vdyn_xchg_wait)
-    int64_t pushes = 0;             // pushes issued over the handle's life; push k records ev_done[k % kPushRing]
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
 
@@ -185,8 +183,7 @@ void vdyn_destroy(VdynHandle *h)
     if (h->d_count) (void)hipFree(h->d_count);
     for (int i = 0; i < VdynHandle::kCopyStreams; ++i) {
         if (h->copy_stream[i]) { (void)hipStreamSynchronize(h->copy_stream[i]); (void)hipStreamDestroy(h->copy_stream[i]); }
-        for (int k = 0; k < VdynHandle::kPushRing; ++k)
-            if (h->ev_done[k][i]) (void)hipEventDestroy(h->ev_done[k][i]);
+        if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
     }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     delete h;
@@ -277,14 +274,14 @@ int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_
     if (!h->ev_ready) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     for (int i = 0; i < ns; ++i) {
         if (!h->copy_stream[i]) VDYN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream[i], hipStreamNonBlocking));
-        for (int k = 0; k < VdynHandle::kPushRing; ++k)
-            if (!h->ev_done[k][i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done[k][i], hipEventDisableTiming));
+        if (!h->ev_done[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
     }
     // Pushes follow each other on the DEVICE: push k + 1's copies sit behind push k's on the same in-order copy
     // streams (a destination always maps to the same stream, so the later block lands last), and what the caller
     // has to protect -- the source block, until the copies have read it -- is a device-side wait too
-    // (vdyn_xchg_fence).  The host never blocks here.
-    hipEvent_t *done = h->ev_done[h->pushes % VdynHandle::kPushRing];
+    // (vdyn_xchg_fence).  The host never blocks here, and a push is one event record plus, per destination, one
+    // stream-wait and one copy: with seven peers the host spends less time queueing a step than the GPU running it
+    // (completion events are recorded by the fence, once per several pushes, not here).
     hipError_t e = hipEventRecord(h->ev_ready, (hipStream_t)after_stream);           // the block is complete ...
     for (int i = 0; i < ns && e == hipSuccess; ++i)
         e = hipStreamWaitEvent(h->copy_stream[i], h->ev_ready, 0);                   // ... before any copy reads it
@@ -297,7 +294,6 @@ int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_
                            h->copy_stream[i % ns]);
         if (e == hipSuccess) ++queued;
     }
-    for (int i = 0; i < ns && e == hipSuccess; ++i) e = hipEventRecord(done[i], h->copy_stream[i]);
     if (e != hipSuccess) {
         // some copies may be queued and still read `src` / write the peers' slots: let them finish before the caller
         // frees or closes anything on this error (best effort: the streams' own errors are not the one reported)
@@ -306,21 +302,17 @@ int vdyn_xchg_push(VdynHandle *h, void *const *dst, int32_t n_dst, uint64_t dst_
         return h->fail_hip("xchg_push", e);
     }
     h->push_streams = std::max(h->push_streams, ns);
-    ++h->pushes;
     return VDYN_OK;
 }
 
-int vdyn_xchg_fence(VdynHandle *h, void *stream, int32_t lag)
+int vdyn_xchg_fence(VdynHandle *h, void *stream)
 {
     if (!h) return VDYN_ERR_ARG;
-    if (lag < 0 || lag >= VdynHandle::kPushRing)
-        return h->fail(VDYN_ERR_ARG, "xchg_fence: lag must be in [0, " + std::to_string(VdynHandle::kPushRing) + ")");
-    const int64_t k = h->pushes - 1 - lag;                      // the push to wait for
-    if (k < 0 || h->push_streams == 0) return VDYN_OK;          // nothing that old (or everything already waited for)
+    if (h->push_streams == 0) return VDYN_OK;                   // nothing pushed since the last vdyn_xchg_wait
     VDYN_HIP(h, hipSetDevice(h->device));
     for (int i = 0; i < h->push_streams; ++i) {
-        hipEvent_t ev = h->ev_done[k % VdynHandle::kPushRing][i];
-        if (ev) VDYN_HIP(h, hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+        VDYN_HIP(h, hipEventRecord(h->ev_done[i], h->copy_stream[i]));              // behind every copy queued so far
+        VDYN_HIP(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_done[i], 0));
     }
     return VDYN_OK;
 }

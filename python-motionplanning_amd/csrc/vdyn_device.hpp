@@ -36,8 +36,9 @@ namespace vdyn {
 // (c in (0, 1]) -- no argument reduction, no branch, no x > 1 case.  The coefficients depend on C, which belongs to
 // the handle: the host fits them when it builds DevParams (make_dev_params, vdyn_kernels.hip) and checks the fp32
 // Horner evaluation against double; W[i][wheel], highest degree first.
-// fp64 (the trimmed scalar step below and the wheel-parallel one): degree 18, W[i][wheel] as well.  Nineteen doubles
-// per wheel fit neither the scalar registers a wave-uniform constant lives in (round 2 kept ONE set, pinned in 38
+// fp64 (the trimmed scalar step below and the wheel-parallel one): degree 16 (2.3e-14; round 3's degree 18 held 1.3e-15 and
+// cost two more fmas per wheel and stage -- tools/fit_tire_w.py, profiles/r04_tire_fit_degrees.txt), W[i][wheel] as
+// well.  Seventeen doubles per wheel fit neither the scalar registers a wave-uniform constant lives in (round 2 kept ONE set, pinned in 34 (then 38)
 // VGPRs, and sent handles whose wheels differ in C to the general chain at half the speed) nor, four times over, the
 // vector file.  So: wheels that share C (the reference's) -> that one set pinned in VGPRs as in round 2 (pin_tire_fit);
 // wheels that differ -> the rollout kernel stages the table in LDS once per workgroup and the step reads it back as
@@ -45,7 +46,7 @@ namespace vdyn {
 // general chain); the wheel-parallel kernel keeps its lane's own wheel's column in registers either way.
 // A handle whose fits fail their check takes the general atan -> sine chain (lane_cs).
 constexpr int kTireFitDeg = 8;
-constexpr int kTireFitDeg64 = 18;
+constexpr int kTireFitDeg64 = 16;
 template <typename T> struct TireFit;
 template <> struct TireFit<float> {
     float W[kTireFitDeg + 1][4];
@@ -107,7 +108,7 @@ __device__ __forceinline__ void stage_tire_fit(const DevParams<double> &)
 }
 
 // fp64 handles whose four wheels share C (the reference's do, vehicle_model.py:44-45): column 0 of the table, moved from
-// the scalar to the vector registers once, at the top of the kernel.  As wave-uniform kernel arguments the nineteen
+// the scalar to the vector registers once, at the top of the kernel.  As wave-uniform kernel arguments the seventeen
 // doubles sit in SGPRs, and together with the other constants of the step they overflow the scalar file: the compiler
 // then spills SGPRs into VGPR lanes and reads them back one `v_readlane_b32` at a time (105 per RK4 step before this,
 // 9 % of the instruction stream).  38 VGPRs is what the vector file has to spare: one set, not four.

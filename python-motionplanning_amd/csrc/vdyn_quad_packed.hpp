@@ -29,7 +29,7 @@ __device__ __forceinline__ f2 pk_rot90(f2 a, f2 b)        // (-a.y b.x, a.x b.x)
 }
 
 template <typename T>
-struct QuadEngine {           // fp64: the scalar step; this lane's wheel's nineteen fit coefficients in registers
+struct QuadEngine {           // fp64: the scalar step; this lane's wheel's seventeen fit coefficients in registers
     T fw[kTireFitDeg64 + 1];
     __device__ __forceinline__ void init(const DevParams<T> &, const WheelLane<T> &, int q)
     {

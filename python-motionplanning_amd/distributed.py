@@ -136,16 +136,16 @@ class PeerExchange:
     later block lands after an earlier one -- and the one thing that needs protecting, the SOURCE block until the
     copies have read it, is protected on the device as well: the last ``2 * HOLD`` sources stay referenced (so the
     caching allocator cannot hand their memory to the next rollout), and every ``HOLD`` exchanges ONE device-side wait
-    (``vdyn_xchg_fence``: the caller's stream waits for the copies of the push ``HOLD`` back, which finished several
-    rollouts ago) releases the ``HOLD`` oldest -- a stream-wait is a barrier packet between two kernels, so it is paid
-    once per ``HOLD`` steps, not per step.  A padded send block rotates through ``2 * HOLD`` buffers under the same
-    fence.  A rank's OWN block is not copied per step at all: ``result`` places the last one in its slot.
+    (``vdyn_xchg_fence``: the caller's stream waits for the copies queued so far -- the newest of them belongs to the
+    rollout before the one just launched and finishes well inside it) releases the ``HOLD`` oldest -- a stream-wait is
+    a barrier packet between two kernels, so it is paid once per ``HOLD`` steps, not per step.  A padded send block
+    rotates through ``2 * HOLD`` buffers under the same fence.  A rank's OWN block is not copied per step at all: ``result`` places the last one in its slot.
     ``wait`` blocks the host until THIS rank's copies have landed; a block pushed by another rank is known to have
     landed once that rank waited and both passed a barrier -- ``result`` and bench.py's fence do exactly that.
     UNMEASURED on more than one GPU (none was available to the build); the 2- and 4-process rehearsals on one GPU
     exercise handles, slots and ordering."""
 
-    HOLD = 4            # 2 * HOLD sources kept alive = the library's ring of completion events (8)
+    HOLD = 4            # 2 * HOLD sources kept alive; one fence per HOLD exchanges
     kind = "peer_copies"
     fallback_reason = None
 
@@ -258,11 +258,10 @@ class PeerExchange:
         assert tuple(term_local.shape) == (self.rows, self.sh.n_local)
         stream = self._C.c_void_p(torch.cuda.current_stream(term_local.device).cuda_stream)
         if len(self._inflight) >= 2 * self.HOLD:
-            # the caller's stream waits, on the device, for the copies of the push HOLD back from the latest: that and
-            # everything older has then been read, so the HOLD oldest sources may be overwritten (the padded send
-            # blocks below) or freed (the allocator reuses memory in stream order, and this wait is ahead of anything
-            # enqueued from here on)
-            self.h.call("vdyn_xchg_fence", stream, self.HOLD)
+            # the caller's stream waits, on the device, for every copy queued so far: all held sources have then been
+            # read, and the HOLD oldest may be overwritten (the padded send blocks below) or freed (the allocator
+            # reuses memory in stream order, and this wait is ahead of anything enqueued from here on)
+            self.h.call("vdyn_xchg_fence", stream)
             del self._inflight[:self.HOLD]
         src = term_local.contiguous()
         if self.send is not None:

@@ -713,10 +713,10 @@ class VehicleModel:
     def tire_fit(shape_factor, dtype=np.float32):
         """The FAST step's fit for one wheel with Pacejka shape factor C (include/vdyn.h,
         ``vdyn_tire_fit_f32`` / ``_f64``; host arithmetic, no device needed): ``(coef, validated)`` --
-        9 float32 or 19 float64 coefficients, highest degree first -- with
+        9 float32 or 17 float64 coefficients, highest degree first -- with
         ``sin(C atan x) / x = c P(c)``, ``c = 1 / sqrt(1 + x^2)``."""
         f32 = np.dtype(dtype) == np.float32
-        coef = np.zeros(9 if f32 else 19, dtype=np.float32 if f32 else np.float64)
+        coef = np.zeros(9 if f32 else 17, dtype=np.float32 if f32 else np.float64)
         fn = _lib.load().vdyn_tire_fit_f32 if f32 else _lib.load().vdyn_tire_fit_f64
         return coef, fn(float(shape_factor), coef.ctypes.data_as(C.c_void_p)) == 0
 

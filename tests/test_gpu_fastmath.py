@@ -83,7 +83,8 @@ def test_packed_forms_of_the_fp32_step(gpu_vm):
 
 
 def test_fitted_tire_chain_fp64(gpu_vm):
-    """fn 5 in fp64: the trimmed scalar step's chain, c = rsq(1 + x^2), degree-18 Horner with the fit of C."""
+    """fn 5 in fp64: the trimmed scalar step's chain, c = rsq(1 + x^2), degree-16 Horner with the fit of C (2.3e-14;
+    degree 18 held 1.3e-15 for two more fmas per wheel and stage: profiles/r04_tire_fit_degrees.txt)."""
     vm = gpu_vm(1e-3)
     x = np.concatenate([[0.0], _grid(-4.0, 4.0, 200001), _grid(1e-8, 1e7, 100000, log=True, both=True)])
     xl = x.astype(np.longdouble)
@@ -94,7 +95,7 @@ def test_fitted_tire_chain_fp64(gpu_vm):
         small = np.abs(xl) <= np.sqrt(3.0)
         gref = np.where(xl != 0, np.sin(c * np.arctan(xl)) / np.where(xl != 0, xl, 1.0), c)
         worst_g = max(worst_g, float((np.abs(g - gref) / np.abs(gref))[small].max()))
-    assert worst <= 4e-15 and worst_g <= 4e-15, f"{worst:.2e} {worst_g:.2e}"
+    assert worst <= 5e-14 and worst_g <= 5e-14, f"{worst:.2e} {worst_g:.2e}"
     print(f"\n  fp64 fitted chain: sin(C atan x) abs {worst:.2e}, G relative {worst_g:.2e}")
 
 

@@ -46,10 +46,11 @@ def test_fit_that_fails_its_check_is_reported(pkg, C):
 
 @pytest.mark.parametrize("C", [1.5047, 0.0, 0.5, 1.0, 1.3, 1.9, 2.0])
 def test_fp64_fit(pkg, C):
-    """Degree 18, 19 coefficients, one set per handle (the four wheels must share C): checked to 4e-15 by the
-    library, here against long-double NumPy with a plain (unfused) Horner loop."""
+    """Degree 16, 17 coefficients (round 3: degree 18; two fmas per wheel and stage bought 1.3e-15 instead of 2.3e-14,
+    profiles/r04_tire_fit_degrees.txt): checked to 5e-14 by the library, here against long-double NumPy with a plain
+    (unfused) Horner loop."""
     coef, ok = pkg.VehicleModel.tire_fit(C, np.float64)
-    assert ok and coef.dtype == np.float64 and coef.shape == (19,)
+    assert ok and coef.dtype == np.float64 and coef.shape == (17,)
     x = np.concatenate([[0.0], np.linspace(0.0, 4.0, 100001), np.geomspace(1e-8, 1e8, 50001)]).astype(np.longdouble)
     c = (1.0 / np.sqrt(1.0 + x * x)).astype(np.float64)
     g = np.full_like(c, coef[0])
@@ -57,6 +58,6 @@ def test_fp64_fit(pkg, C):
         g = g * c + a
     G = (g * c).astype(np.longdouble)
     want = np.where(x > 0, np.sin(C * np.arctan(x)) / np.where(x > 0, x, 1.0), C)
-    assert np.max(np.abs(G - want) * x) <= 4e-15
+    assert np.max(np.abs(G - want) * x) <= 5e-14
     small = x <= np.sqrt(3.0)
-    assert np.max((np.abs(G - want) / np.maximum(np.abs(want), 1e-300))[small]) <= 4e-15
+    assert np.max((np.abs(G - want) / np.maximum(np.abs(want), 1e-300))[small]) <= 5e-14
