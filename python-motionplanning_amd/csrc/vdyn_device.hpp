@@ -42,7 +42,7 @@ namespace vdyn {
 // VGPRs, and sent handles whose wheels differ in C to the general chain at half the speed) nor, four times over, the
 // vector file.  So: wheels that share C (the reference's) -> that one set pinned in VGPRs as in round 2 (pin_tire_fit);
 // wheels that differ -> the rollout kernel stages the table in LDS once per workgroup and the step reads it back as
-// it goes (fit_horner4_lds: 152 more instructions per step, 0.56 against 0.42 ms on configs[1], against 0.87 for the
+// it goes (fit_horner4_lds: 136 more instructions per step, 0.51 against 0.39 ms on configs[1], against 0.87 for the
 // general chain); the wheel-parallel kernel keeps its lane's own wheel's column in registers either way.
 // A handle whose fits fail their check takes the general atan -> sine chain (lane_cs).
 constexpr int kTireFitDeg = 8;
@@ -84,12 +84,12 @@ __device__ __forceinline__ vdyn_fit_table fit_table_kernarg()
     return (vdyn_fit_table)__builtin_amdgcn_kernarg_segment_ptr();
 }
 
-// W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(18 - i).  The coefficients come from the
+// W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(16 - i).  The coefficients come from the
 // kernel-argument table two degrees (eight doubles = one s_load_dwordx16) at a time; the opaque pointer in front of
-// each group keeps the compiler from collecting all 76 of them at the top of the kernel, where they do not fit the
+// each group keeps the compiler from collecting all 68 of them at the top of the kernel, where they do not fit the
 // scalar file (105 v_readlane per step before round 2's fix), while each group's load still goes out ahead of the
 // previous group's eight fmas.
-// The lane kernels' copy of that table in LDS: 76 doubles, staged once per workgroup (stage_tire_fit), read back by
+// The lane kernels' copy of that table in LDS: 68 doubles, staged once per workgroup (stage_tire_fit), read back by
 // every lane at the same address -- a broadcast, no bank conflict.
 typedef double __attribute__((address_space(3))) *vdyn_lds_f64;
 __device__ __forceinline__ vdyn_lds_f64 fit_table_lds()
@@ -111,10 +111,10 @@ __device__ __forceinline__ void stage_tire_fit(const DevParams<double> &)
 // the scalar to the vector registers once, at the top of the kernel.  As wave-uniform kernel arguments the seventeen
 // doubles sit in SGPRs, and together with the other constants of the step they overflow the scalar file: the compiler
 // then spills SGPRs into VGPR lanes and reads them back one `v_readlane_b32` at a time (105 per RK4 step before this,
-// 9 % of the instruction stream).  38 VGPRs is what the vector file has to spare: one set, not four.
+// 9 % of the instruction stream).  34 VGPRs (38 at round 3's degree 18) is what the vector file has to spare: one set, not four.
 __device__ __forceinline__ void pin_tire_fit(DevParams<float> &) {}
 // One C per axle (front tires of one kind, rear tires of another -- the usual way a vehicle's wheels differ): columns
-// 0 and 2, both pinned (FITSRC 3).  76 VGPRs; the step still needs no accumulation register and no LDS read.
+// 0 and 2, both pinned (FITSRC 3).  68 VGPRs; the step still needs no accumulation register and no LDS read.
 __device__ __forceinline__ void pin_tire_fit_axles(DevParams<float> &) {}
 __device__ __forceinline__ void pin_tire_fit_axles(DevParams<double> &P)
 {
@@ -125,7 +125,7 @@ __device__ __forceinline__ void pin_tire_fit_axles(DevParams<double> &P)
     }
 }
 
-// W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(18 - i), the coefficients read from the
+// W_C(c) of the four wheels at once, Horner, fp64: g[k] = sum_i W[i][k] c_k^(16 - i), the coefficients read from the
 // LDS table one degree (four doubles, two 16-byte reads) at a time.  Tried first: scalar loads straight from the
 // kernel-argument segment, the coefficient as the fma's scalar operand, two groups in flight -- no VGPR, no LDS, and
 // 0.64 ms instead of 0.42 on configs[1]: a scalar-cache hit is ~200 cycles, far more than the eight fp64 fmas it
@@ -137,12 +137,12 @@ __device__ __forceinline__ void fit_horner4_lds(const double cc[4], double g[4])
 {
     // Groups of kG degrees (2 kG 16-byte reads, 8 kG VGPRs), kAhead groups read ahead of the one being evaluated: a
     // group's reads may not start before all four chains have finished the group kAhead + 1 before it (the asm in
-    // front of them takes the chains as inputs).  Left alone, the scheduler issues the 38 reads of an evaluation at
-    // once, and the 152 registers they fill push the step into scratch.
+    // front of them takes the chains as inputs).  Left alone, the scheduler issues the 34 reads of an evaluation at
+    // once, and the 136 registers they fill push the step into scratch.
     typedef const vdyn_d2v __attribute__((address_space(3))) *lds_ptr;     // stays an LDS address (32 bits), never a flat one
     const lds_ptr t0 = (lds_ptr)fit_table_lds();
     constexpr int kSlots = kAhead + 1;
-    constexpr int kRest = kTireFitDeg64 + 1 - 2;                       // degrees 2 .. 18
+    constexpr int kRest = kTireFitDeg64 + 1 - 2;                       // coefficients 2 .. kTireFitDeg64
     constexpr int kGroups = kRest / kG;                                // the last group takes the remainder too
     constexpr int kLast = kRest - (kGroups - 1) * kG;
     vdyn_d2v w[kSlots][2 * (kG + kG - 1)];

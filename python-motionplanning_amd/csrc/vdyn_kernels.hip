@@ -435,7 +435,7 @@ rollout_spiral_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ st
 // class -- every BASELINE configuration -- the constants are wave-uniform and the kernel above
 // keeps them in SGPRs instead, which is cheaper than any LDS read.)
 // One class of the fleet table, as plain T words.  fp32: the whole DevParams (its per-wheel fits are 36 floats).  fp64:
-// ONE set of fit coefficients + the rest -- 76 doubles of per-wheel fits per class would neither fit LDS for 256
+// ONE set of fit coefficients + the rest -- 68 doubles of per-wheel fits per class would neither fit LDS for 256
 // classes nor a lane's registers, so an fp64 class takes the fitted chain only when its four wheels share C
 // (build_fleet_table) and the lane carries that set as column 0 of its DevParams.
 template <typename T> struct FleetRow;
@@ -999,7 +999,7 @@ closed_loop_kernel(DevParams<T> P, CtrlGains<T> G, int64_t n, int H, int ctrl_ev
                    T *__restrict__ terminal, T *__restrict__ cstate, T *__restrict__ log,
                    T *__restrict__ datalog, const T *__restrict__ aux)
 {
-    // fp64 with the DataLog: the step that also averages the 28 diagnostics has no 38 VGPRs left for a pinned fit (it
+    // fp64 with the DataLog: the step that also averages the 28 diagnostics has no 34 VGPRs left for a pinned fit (it
     // spilled 250-380 bytes per lane to scratch) -- it reads the table from LDS instead (fit_horner4_lds)
     constexpr bool kFitLds = DATALOG && sizeof(T) == 8;
     if (CS) {                           // only the fitted chain reads them
