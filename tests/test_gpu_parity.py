@@ -278,6 +278,40 @@ def test_step_chain_equals_rollout_and_traj(gpu_vm, workloads):
     assert np.array_equal(s, term)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_trajectory_rows_ragged_chunked_odd(gpu_vm, workloads, dtype):
+    """The trajectory writer (RowWriter, csrc/vdyn_kernels.hip: wave-uniform row base, 32-bit lane and column offsets,
+    idle lanes of the last workgroup shadowing rollout n - 1, two steps per loop trip) where its bookkeeping has edges:
+    sizes that are not whole workgroups (one lane, one wave + 1, three workgroups + 231), a shared table longer than
+    one LDS chunk (H = 901: chunks of 438 + 438 + 25, so a chunk ends on an odd step and the one-step tail runs), every
+    stride against the horizon (1, 2, 7, 450, H).  Every trajectory row must equal, bit for bit, the terminal state of
+    a rollout of exactly that many steps, and per-rollout controls write the same rows."""
+    import torch
+    dev = torch.device("cuda:0")
+    H, nmax = 901, 999
+    s0, tab, pid = workloads.config3(nmax, H, dtype)
+    vm = gpu_vm(1e-3)
+    for n in (1, 65, 999):
+        a, b = np.ascontiguousarray(s0[:, :n]), pid[:n].copy()
+        for stride in (1, 2, 7, 450, H):
+            rows = H // stride
+            term, traj = vm.rollout(torch.from_numpy(a).to(dev), torch.from_numpy(tab).to(dev),
+                                    path_id=torch.from_numpy(b).to(dev), traj_stride=stride)
+            traj = traj.cpu().numpy()
+            assert traj.shape == (rows, 12, n) and np.isfinite(traj).all()
+            for j in sorted({0, rows // 2, rows - 1}):
+                want = vm.rollout(a, tab[:, :(j + 1) * stride], path_id=b)
+                assert np.array_equal(traj[j], want), (n, stride, j)
+            assert np.array_equal(term.cpu().numpy(), vm.rollout(a, tab, path_id=b))
+    # per-rollout controls (no LDS table, global loads a step ahead) write the same rows
+    n = 300
+    a, b = np.ascontiguousarray(s0[:, :n]), pid[:n].copy()
+    ctrl = workloads.expand_shared_controls(tab, b)
+    t1, tr1 = vm.rollout(a, tab, path_id=b, traj_stride=7)
+    t2, tr2 = vm.rollout(a, ctrl, traj_stride=7)
+    assert np.array_equal(tr1, tr2) and np.array_equal(t1, t2)
+
+
 def test_permutation_invariance_and_ragged_sizes(gpu_vm, workloads):
     s0, tab, pid = workloads.config3(1000, 40)
     vm = gpu_vm(1e-3)
