@@ -77,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 code path (RCCL all-gather of terminal states, overlapped with the "
                          "next launch) even with one rank: rehearsal of the multi-GPU path on a 1-GPU box")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="--exchange auto: skip the untimed comparison of peer copies and all-gather that picks the "
+                         "exchange of the timed region (peer copies are then used whenever they can be set up)")
     ap.add_argument("--no-sections", action="store_true",
                     help="N>1 (or --force-collective): skip what follows the timed region -- `exchange_ab` (RCCL vs peer "
                          "copies, K/2 steps each) and `strong` (the fixed-65536 split, lane and wheel-parallel kernels)")
@@ -439,6 +442,26 @@ def run(args, compute_factory=None):
     job = make_job(n_total)
     sh, n_local, tab = job.sh, job.n_local, job.tab
     xch = D.make_exchange(args.exchange, sh, rows=12, like=job.s0, handle=cp.handle()) if collective else None
+    calibration = None
+    if collective and args.exchange == "auto" and xch.kind == "peer_copies" and not args.no_calibration:
+        # `auto`, second half: the peer copies have never run across devices where this was built, so whether they or
+        # the RCCL all-gather cost the step less is MEASURED here, before the timed region, on the very job that
+        # follows: a few untimed steps with each, the maximum over the ranks (so every rank sees the same two numbers
+        # and takes the same decision); the peer copies stay unless the collective is clearly faster
+        alt = D.AllGatherExchange(sh, 12, job.s0)
+        n_cal = max(4, min(16, args.steps))
+        t_p2p = timed_steps(job, cp, xch, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
+        t_rccl = timed_steps(job, cp, alt, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
+        calibration = {"steps": n_cal, "peer_copies_ms_per_step": t_p2p * 1e3, "all_gather_ms_per_step": t_rccl * 1e3,
+                       "rule": "peer copies unless the all-gather is more than 3 % faster"}
+        if t_rccl < 0.97 * t_p2p:
+            xch.close()
+            xch, alt = alt, None
+            xch.fallback_reason = (f"calibration: all-gather {t_rccl * 1e3:.4f} ms per step against "
+                                   f"{t_p2p * 1e3:.4f} ms with peer copies")
+        else:
+            alt.close()
+        calibration["chosen"] = xch.kind
     m = timed_steps(job, cp, xch, args.steps, args.warmup, overlap=not args.no_overlap, prewarm_ms=args.prewarm_ms)
     term, elapsed = m.term, m.elapsed
     gathered_ok = None
@@ -470,6 +493,7 @@ def run(args, compute_factory=None):
         "value_excluding_collective": n_total * H / kern_s,
         "world_seen": sh.world, "dist_backend": getattr(cp, "backend", None) if collective else None,
         "rollouts_total": n_total, "shards": [list(b) for b in sh.bounds],
+        "exchange_calibration": calibration,
         "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
                                                  "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok,
                                                  "verified_how": VERIFIED_HOW,
@@ -546,6 +570,8 @@ def run(args, compute_factory=None):
 
     strong_full = None
     if collective and not args.no_sections:
+        # the fixed-N split below uses what the headline used (after `auto`'s calibration, that may be the collective)
+        strong_exchange = "rccl" if args.exchange == "auto" and xch.kind != "peer_copies" else args.exchange
         xch.close()
         xch = None
         k_ab, w_ab = max(1, args.steps // 2), max(1, args.warmup // 2)
@@ -586,7 +612,7 @@ def run(args, compute_factory=None):
             st["shards"] = [list(b) for b in job_s.sh.bounds]
             for name, lanes_s in (("lane", 1), ("wheel_parallel", 4)):
                 cpx = cp if lanes_s == lanes else cp.with_lanes(lanes_s)
-                x = D.make_exchange(args.exchange, job_s.sh, rows=12, like=job_s.s0, handle=cpx.handle())
+                x = D.make_exchange(strong_exchange, job_s.sh, rows=12, like=job_s.s0, handle=cpx.handle())
                 r = timed_steps(job_s, cpx, x, k_ab, w_ab)
                 ok, full = verify(job_s, cpx, x, r.term)
                 st[name] = {"ms_per_step": r.elapsed / k_ab * 1e3, "value": n_s * H * k_ab / r.elapsed,
@@ -882,6 +908,20 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
     t = (time.perf_counter() - t0) / 400
     ex["two_streams_65536x200_f32"] = {"steps_per_s": n / t, "ms_per_launch": t * 1e3,
                                        "note": "independent batches alternating between two HIP streams (wall time)"}
+    # what a caller gets WITHOUT the bench's clock ramp: the same launch right after the GPU has sat idle (the timed
+    # region above follows 250 ms of load; an idle MI355X starts at ~2.06 GHz and needs tens of ms to reach 2.43)
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+    ev[0].record()
+    for i in range(20):
+        vm.rollout(s0, tabd2, path_id=pid)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    cold = [ev[i].elapsed_time(ev[i + 1]) for i in range(20)]
+    ex["after_idle_65536x200_f32"] = {"first_launch_ms": cold[0], "mean_of_first_20_ms": float(np.mean(cold)),
+                                      "steps_per_s_first_20": n * 20 / (sum(cold) * 1e-3),
+                                      "note": "0.5 s idle, no warm-up, an event pair per launch"}
     # occupancy sweep of the main kernel: where the chip fills up
     sweep = {}
     for mult in (2, 4, 8):

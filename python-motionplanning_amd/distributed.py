@@ -139,7 +139,8 @@ class PeerExchange:
     (``vdyn_xchg_fence``: the caller's stream waits for the copies queued so far -- the newest of them belongs to the
     rollout before the one just launched and finishes well inside it) releases the ``HOLD`` oldest -- a stream-wait is
     a barrier packet between two kernels, so it is paid once per ``HOLD`` steps, not per step.  A padded send block
-    rotates through ``2 * HOLD`` buffers under the same fence.  A rank's OWN block is not copied per step at all: ``result`` places the last one in its slot.
+    rotates through ``2 * HOLD`` buffers under the same fence.  A rank's OWN block is not copied per step at all:
+    ``result`` places the last one in its slot.
     ``wait`` blocks the host until THIS rank's copies have landed; a block pushed by another rank is known to have
     landed once that rank waited and both passed a barrier -- ``result`` and bench.py's fence do exactly that.
     UNMEASURED on more than one GPU (none was available to the build); the 2- and 4-process rehearsals on one GPU
@@ -218,7 +219,7 @@ class PeerExchange:
             self.recv = torch.as_tensor(_DeviceBuffer(self._own, (sh.world * self.rows, sh.n_pad), typestr),
                                         device=like.device)
             self.recv.zero_()
-            # a rank holding fewer egos than the largest shard sends a zero-padded block; two of them, alternating
+            # a rank holding fewer egos than the largest shard sends a zero-padded block; 2 * HOLD of them, in rotation
             self.send = [like.new_zeros((self.rows, sh.n_pad)) for _ in range(2 * self.HOLD)] if sh.n_local != sh.n_pad else None
             # the zero fill must have RUN before a peer can learn this buffer's handle: its first push could
             # otherwise land before the fill and be wiped by it

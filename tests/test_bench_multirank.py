@@ -61,6 +61,7 @@ def test_bench_two_ranks_shard_by_whole_egos_and_gather_bitwise(tmp_path, mode, 
         assert st[k]["verified"] is True and st[k]["ms_per_step"] > 0 and st[k]["lanes_per_rollout"] == ln
     assert out["roofline_hbm"]["frac"] > 0 and out["roofline_hbm"]["per_gpu"] is True and out["roofline"]["per_gpu"] is True
     assert "sections_timed_out" not in out and "_section" not in out
+    assert out["exchange_calibration"] is None       # CPU stand-in: no peer copies to compare the collective with
     # what every rank holds after the last exchange == the single-process result, bit for bit
     s0, tab, pid = workloads.config3(n_total, 12, np.float32)
     single = oracle.rollout(oracle.default_params(), s0.astype(np.float64), tab.astype(np.float64), 1e-3,

@@ -124,6 +124,11 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
                                "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4, "verified": True,
                                "requested": exchange, "fallback_reason": None}
     assert out["value"] > 0 and out["roofline"]["bound"] == "valu" and "cpu_baseline" not in out
+    cal = out["exchange_calibration"]
+    if exchange == "auto":      # measured before the timed region: peer copies against the all-gather, same on every rank
+        assert cal["chosen"] == out["exchange"]["kind"] and cal["peer_copies_ms_per_step"] > 0 and cal["all_gather_ms_per_step"] > 0
+    else:
+        assert cal is None
     s0, tab, pid = workloads.config3(n_total, 50, np.float32)
     dev = torch.device("cuda:0")
     single = gpu_vm(1e-3).rollout(torch.from_numpy(s0).to(dev), torch.from_numpy(tab).to(dev),
@@ -162,6 +167,7 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
                                "requested": exchange, "fallback_reason": None}
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
     assert out["roofline"]["bound"] == "valu" and out["shards"] == [[0, 65536]]
+    assert (out["exchange_calibration"] is not None) == (exchange == "auto")
     # the sections an 8-GPU run adds to its one line: RCCL and peer copies side by side, the fixed-65536 split with both
     # kernels -- each verified -- and the per-GPU HBM roofline
     ab, st = out["exchange_ab"], out["strong"]
