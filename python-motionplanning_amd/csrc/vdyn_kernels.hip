@@ -218,6 +218,52 @@ __device__ __forceinline__ void put_state12(const ROW &row, const STATE &X)
 {
     put_cols<T, 0, 12>(row, [&](int i) __attribute__((always_inline)) { return X.get(i); });
 }
+// The reading counterpart for per-rollout controls [H][K][n] (LAYOUT 0): the rows of step t + 1 follow those of step t
+// in memory, so the step loop keeps a wave-uniform running base (a buffer descriptor advanced by the pitch with two
+// scalar adds) where `ctrl + t K n + r` per lane was a 64-bit scalar multiply (eight SALU instructions: there is no
+// 64-bit s_mul) and a `v_lshl_add_u64` per row -- twelve issue slots per step for two loads, now six.  Rows are read
+// strictly in order, one load() per step; the caller never loads past row H - 1.  Same precondition as RowWriter
+// (K n sizeof(T) <= 2^31, `fits`), checked by the kernel itself: a larger batch keeps the per-lane addresses.
+template <typename T, int K>
+struct RowReader {
+    const char *base;           // wave-uniform: the workgroup's first column of the row the next load() reads
+    int64_t pitch;              // bytes from one step's rows to the next: K n sizeof(T)
+    uint32_t voff;              // lane: bytes from `base`
+    uint32_t soff[K];           // wave-uniform: bytes of row i of a step
+    static __device__ __forceinline__ bool fits(int64_t n) { return (int64_t)K * n * (int64_t)sizeof(T) <= ((int64_t)1 << 31); }
+    __device__ __forceinline__ RowReader(const T *ctrl, int64_t r, int64_t n, int t)
+        : base(reinterpret_cast<const char *>(ctrl + (int64_t)blockIdx.x * kBlock + (int64_t)t * K * n)),
+          pitch((int64_t)K * n * (int64_t)sizeof(T)),
+          voff((uint32_t)(r - (int64_t)blockIdx.x * kBlock) * (uint32_t)sizeof(T))
+    {
+#pragma unroll
+        for (int i = 0; i < K; ++i) soff[i] = (uint32_t)i * (uint32_t)n * (uint32_t)sizeof(T);
+    }
+    template <int I>
+    __device__ __forceinline__ T row(__amdgpu_buffer_rsrc_t rs) const
+    {
+        if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff[I], 0));
+        else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff[I], 0));
+    }
+    // the controls of the current row into c (as Ctrl::set would), then on to the next row
+    __device__ __forceinline__ void load(const DevParams<T> &P, Ctrl<T, K> &c)
+    {
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, 0x7fffffff, 0x00020000);
+        if constexpr (K == 2) {
+            c.delta[0] = c.delta[1] = row<0>(rs);
+            c.delta[2] = c.delta[3] = T(0);
+            const T t = row<1>(rs);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c.tq[i] = t; c.mu[i] = P.mu[i]; }
+        } else {
+            c.delta[0] = row<0>(rs); c.delta[1] = row<1>(rs); c.delta[2] = row<2>(rs); c.delta[3] = row<3>(rs);
+            c.tq[0] = row<4>(rs); c.tq[1] = row<5>(rs); c.tq[2] = row<6>(rs); c.tq[3] = row<7>(rs);
+            c.mu[0] = row<8>(rs); c.mu[1] = row<9>(rs); c.mu[2] = row<10>(rs); c.mu[3] = row<11>(rs);
+        }
+        base += pitch;
+    }
+};
 // PW (fp64, CS): the four wheels differ in C -- the per-wheel fit table goes to LDS and the step reads it from there
 // (fit_horner4_lds); otherwise the handle's one set is pinned in VGPRs (pin_tire_fit).
 // COMP (fp32, CS): state0 / terminal are [22][n], rows 12..21 the compensation terms of the state sum
@@ -286,6 +332,29 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
         Ctrl<T, K> c;
         fetch(c, 0);
         int tc = 0;
+        if constexpr (LAYOUT == 0 && !DIAG && !TRAJ) {
+            // per-rollout controls: rows read strictly in order through a running wave-uniform base (RowReader); the
+            // trip's last load is row tc + 4, so the loop stops while that row exists and the one-step loop below
+            // finishes the horizon
+            if (RowReader<T, K>::fits(n)) {
+                RowReader<T, K> rd(ctrl, r, n, t0 + 1);
+                Ctrl<T, K> c2;
+                for (; tc + 4 < tc_n; tc += 4) {
+                    rd.load(P, c2);
+                    VDYN_FETCH_FENCE
+                    eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                    rd.load(P, c);
+                    VDYN_FETCH_FENCE
+                    eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                    rd.load(P, c2);
+                    VDYN_FETCH_FENCE
+                    eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c.delta, c.tq, c.mu, h, c.sd0, c.cd0);
+                    rd.load(P, c);
+                    VDYN_FETCH_FENCE
+                    eng.template advance_state<K == 2, CS, PRE, FS, COMP>(P, X, c2.delta, c2.tq, c2.mu, h, c2.sd0, c2.cd0);
+                }
+            }
+        }
         if (!DIAG && !TRAJ) {
             // Four steps per trip: the control sets ping-pong (no copy), the loop's one taken branch -- tens of cycles
             // for a lone wave -- is paid every fourth step and the scheduler overlaps a step's tail with the next
