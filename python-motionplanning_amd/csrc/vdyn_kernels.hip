@@ -332,13 +332,15 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
         Ctrl<T, K> c;
         fetch(c, 0);
         int tc = 0;
-        if constexpr (LAYOUT == 0 && K == 2 && !DIAG && !TRAJ) {
+        if constexpr (LAYOUT == 0 && K == 2 && sizeof(T) == 4 && !DIAG && !TRAJ) {
             // per-rollout controls: rows read strictly in order through a running wave-uniform base (RowReader); the
             // trip's last load is row tc + 4, so the loop stops while that row exists and the one-step loop below
             // finishes the horizon.  k = 2 only: with k = 12 the twelve scalar row offsets do not fit the scalar file
             // beside the step's constants, and the fp64 k = 12 instance -- which has no register to spare, 256 VGPRs
             // + 172 AGPRs -- returned wrong x / y rows with the reader (tests/test_gpu_soak.py found it; fp32 k = 12
-            // and every k = 2 instance were right): k = 12 keeps the per-lane addresses.
+            // and every k = 2 instance were right): k = 12 keeps the per-lane addresses.  fp32 only: measured on one box,
+            // fp32 0.1621 -> 0.1577 ms (65536 x 200), fp64 configs[1] 0.3905 -> 0.3923 (64 waves: nothing to gain from
+            // issue slots, and the loads came back a little later).
             if (RowReader<T, K>::fits(n)) {
                 RowReader<T, K> rd(ctrl, r, n, t0 + 1);
                 Ctrl<T, K> c2;
