@@ -312,6 +312,35 @@ def test_trajectory_rows_ragged_chunked_odd(gpu_vm, workloads, dtype):
     assert np.array_equal(tr1, tr2) and np.array_equal(t1, t2)
 
 
+@pytest.mark.parametrize("k", [2, 12])
+def test_per_rollout_controls_with_safe_redo_lanes(gpu_vm, oracle, k):
+    """Per-rollout controls [H][k][N] read a step ahead (k = 2 in fp32: through RowReader's running wave-uniform base)
+    while some lanes of every wave leave the FAST step's validated range (steering beyond pi/4) and are re-integrated
+    by the SAFE step behind its wave-uniform branch: the loads in flight must survive that detour.  Round 4's first
+    RowReader broke exactly this in the fp64 k = 12 instance (x / y rows off by their whole scale) and only the soak
+    test noticed; this is the direct form -- both precisions, every state row, against the oracle."""
+    rng = np.random.default_rng(4 + k)
+    n, H, dt = 640, 23, 1e-3
+    s0 = np.zeros((12, n))
+    s0[0] = rng.uniform(12, 30, n)
+    s0[1], s0[2] = rng.normal(0, 0.5, n), rng.normal(0, 0.3, n)
+    s0[3:7] = s0[0] / 0.308309813617345 * rng.uniform(0.97, 1.03, (4, n))
+    s0[7] = rng.uniform(-np.pi, np.pi, n)
+    s0[8:10] = rng.uniform(-400, 400, (2, n))
+    steer = rng.uniform(-0.3, 0.3, (H, n))
+    steer[:, ::3] = rng.uniform(0.8, 0.9, (H, (n + 2) // 3)) * rng.choice([-1, 1], (H, (n + 2) // 3))   # SAFE lanes
+    if k == 2:
+        c = np.stack([steer, rng.uniform(-300, 600, (H, n))], axis=1)
+    else:
+        c = np.concatenate([np.stack([steer, steer, 0.05 * steer, -0.05 * steer], axis=1),
+                            rng.uniform(-300, 600, (H, 4, n)), rng.uniform(0.6, 1.1, (H, 4, n))], axis=1)
+    vm = gpu_vm(dt)
+    want = oracle.rollout(oracle.default_params(), s0, c, dt)
+    assert np.isfinite(want).all()
+    assert parity(vm.rollout(s0, c), want, F64_TOL, f"fp64 k = {k}, SAFE lanes") <= 1e-9
+    assert parity(vm.rollout(s0.astype(np.float32), c.astype(np.float32)), want, 1e-3, f"fp32 k = {k}, SAFE lanes") <= 1e-3
+
+
 def test_permutation_invariance_and_ragged_sizes(gpu_vm, workloads):
     s0, tab, pid = workloads.config3(1000, 40)
     vm = gpu_vm(1e-3)
