@@ -339,6 +339,12 @@ def test_per_rollout_controls_with_safe_redo_lanes(gpu_vm, oracle, k):
     assert np.isfinite(want).all()
     assert parity(vm.rollout(s0, c), want, F64_TOL, f"fp64 k = {k}, SAFE lanes") <= 1e-9
     assert parity(vm.rollout(s0.astype(np.float32), c.astype(np.float32)), want, 1e-3, f"fp32 k = {k}, SAFE lanes") <= 1e-3
+    # the same launches writing every state (RowWriter's buffer stores beside the redo), fp64 and fp32
+    _, wtraj = oracle.rollout(oracle.default_params(), s0, c, dt, traj_stride=1)
+    t64, traj64 = vm.rollout(s0, c, traj_stride=1)
+    assert parity(traj64, wtraj, F64_TOL, f"fp64 k = {k}, trajectory with SAFE lanes") <= 1e-9 and parity(t64, want, F64_TOL) <= 1e-9
+    t32, traj32 = vm.rollout(s0.astype(np.float32), c.astype(np.float32), traj_stride=1)
+    assert parity(traj32, wtraj, 1e-3, f"fp32 k = {k}, trajectory with SAFE lanes") <= 1e-3
 
 
 def test_permutation_invariance_and_ragged_sizes(gpu_vm, workloads):
