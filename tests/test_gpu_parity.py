@@ -345,6 +345,16 @@ def test_per_rollout_controls_with_safe_redo_lanes(gpu_vm, oracle, k):
     assert parity(traj64, wtraj, F64_TOL, f"fp64 k = {k}, trajectory with SAFE lanes") <= 1e-9 and parity(t64, want, F64_TOL) <= 1e-9
     t32, traj32 = vm.rollout(s0.astype(np.float32), c.astype(np.float32), traj_stride=1)
     assert parity(traj32, wtraj, 1e-3, f"fp32 k = {k}, trajectory with SAFE lanes") <= 1e-3
+    # ... and with the controls as a table shared through LDS (nine paths, three of them beyond pi/4)
+    P = 9
+    tab = np.ascontiguousarray(np.transpose(c[:, :, :P], (2, 0, 1)))            # [P][H][k]: rollouts 0 .. 8 as paths
+    pid = (np.arange(n) % P).astype(np.int32)
+    wterm, wtraj = oracle.rollout(oracle.default_params(), s0, tab, dt, path_id=pid, traj_stride=1)
+    for dtype, tol, bar in ((np.float64, F64_TOL, 1e-9), (np.float32, 1e-3, 1e-3)):
+        t, tr = vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid, traj_stride=1)
+        assert parity(tr, wtraj, tol, f"{np.dtype(dtype).name} k = {k}, shared table, trajectory, SAFE lanes") <= bar
+        assert parity(t, wterm, tol) <= bar
+        assert np.array_equal(vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid), t)
 
 
 def test_permutation_invariance_and_ragged_sizes(gpu_vm, workloads):
