@@ -448,19 +448,22 @@ def run(args, compute_factory=None):
         # the RCCL all-gather cost the step less is MEASURED here, before the timed region, on the very job that
         # follows: a few untimed steps with each, the maximum over the ranks (so every rank sees the same two numbers
         # and takes the same decision); the peer copies stay unless the collective is clearly faster
-        alt = D.AllGatherExchange(sh, 12, job.s0)
         n_cal = max(4, min(16, args.steps))
-        t_p2p = timed_steps(job, cp, xch, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
-        t_rccl = timed_steps(job, cp, alt, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
-        calibration = {"steps": n_cal, "peer_copies_ms_per_step": t_p2p * 1e3, "all_gather_ms_per_step": t_rccl * 1e3,
-                       "rule": "peer copies unless the all-gather is more than 3 % faster"}
-        if t_rccl < 0.97 * t_p2p:
-            xch.close()
-            xch, alt = alt, None
-            xch.fallback_reason = (f"calibration: all-gather {t_rccl * 1e3:.4f} ms per step against "
-                                   f"{t_p2p * 1e3:.4f} ms with peer copies")
-        else:
-            alt.close()
+        try:
+            alt = D.AllGatherExchange(sh, 12, job.s0)
+            t_p2p = timed_steps(job, cp, xch, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
+            t_rccl = timed_steps(job, cp, alt, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
+            calibration = {"steps": n_cal, "peer_copies_ms_per_step": t_p2p * 1e3, "all_gather_ms_per_step": t_rccl * 1e3,
+                           "rule": "peer copies unless the all-gather is more than 3 % faster"}
+            if t_rccl < 0.97 * t_p2p:
+                xch.close()
+                xch, alt = alt, None
+                xch.fallback_reason = (f"calibration: all-gather {t_rccl * 1e3:.4f} ms per step against "
+                                       f"{t_p2p * 1e3:.4f} ms with peer copies")
+            else:
+                alt.close()
+        except Exception as e:                      # noqa: BLE001 -- the exchange already set up and tested stays
+            calibration = {"steps": n_cal, "error": repr(e)}
         calibration["chosen"] = xch.kind
     m = timed_steps(job, cp, xch, args.steps, args.warmup, overlap=not args.no_overlap, prewarm_ms=args.prewarm_ms)
     term, elapsed = m.term, m.elapsed
