@@ -248,6 +248,16 @@ def test_closed_loop_search_on_adversarial_tables(gpu_vm, pkg, oracle):
     assert np.isfinite(idx4).all() and (idx4 >= 0).all() and (idx4 < wc[4]).all(), "fp32 target index out of the NaN table's range"
     assert np.isfinite(log32[:, 12][:, t4]).all() and np.abs(log32[:, 12][:, t4]).max() <= np.deg2rad(30) + 1e-6
     assert np.isfinite(t32[:, t4]).all() and np.isfinite(c32[:, t4]).all(), "fp32 state on the NaN table must stay finite"
+    # the same table through the single-update entry point (tables in global memory, cumulative arcs from
+    # waypoint_cumsum_kernel: the other fp32 lookahead path): finite, in range, and the float oracle's index
+    cs_u, out_u = vm.controller_update(s0.astype(np.float32), c0.astype(np.float32), wp.astype(np.float32), wcount=wc, path_id=pid)
+    assert np.isfinite(out_u[:, t4]).all() and (out_u[1, t4] >= 0).all() and (out_u[1, t4] < wc[4]).all()
+    far_off = 0
+    for i in np.where(t4)[0]:
+        _, jf, _ = oracle.stanley_control(cp, wp[4, :wc[4]].astype(np.float32), np.float32(s0[8, i]), np.float32(s0[9, i]),
+                                          np.float32(s0[7, i]), np.float32(s0[0, i]), dtype=np.float32)
+        far_off += abs(int(out_u[1, i]) - jf) > 1
+    assert far_off <= 0.02 * t4.sum(), f"{far_off} of {int(t4.sum())} single updates on the NaN table miss the float oracle's index"
     ok32 = ok & np.isfinite(t32).all(axis=0)
     off4 = (np.abs(log32[::10, 14][:, t4] - olog32[::10, 14][:, t4]) > 1).mean()
     print(f"\n  NaN-waypoint table, fp32: finite, in range, indices more than one off the float oracle's on {off4:.2%}")
