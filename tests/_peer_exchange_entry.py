@@ -27,13 +27,16 @@ if __name__ == "__main__":
     pidd = torch.from_numpy(pid[sh.lo:sh.hi].copy()).to(dev)
     tabd = torch.from_numpy(tab).to(dev)
     x = D.make_exchange("p2p", sh, 12, s0d, handle=vm.handle())
-    # Four exchanges back to back, no host wait in between (the steady state of bench.py's step): three blocks of
+    # Twelve exchanges back to back, no host wait in between (the steady state of bench.py's step): eleven blocks of
     # distinct constants, then the real terminal states.  Pushes follow each other on the device, so the LAST one
-    # wins in every slot of every rank; the sources of the earlier ones are released behind a device-side fence.
+    # wins in every slot of every rank; more than 2 * HOLD of them, so the device-side fence runs (at the ninth) and
+    # releases the oldest sources, and a padded send block (ragged n) is reused after a full turn of its ring.
     term = vm.rollout(s0d, tabd, path_id=pidd)
-    for it in range(3):
+    assert 11 > 2 * x.HOLD
+    for it in range(11):
         x.start(torch.full_like(term, float(100 * (rank + 1) + it)))
     x.start(term)
+    assert len(x._inflight) <= 2 * x.HOLD, "the fence must have released the oldest sources"
     full = x.result()
     # ... and once more after a result(): slots are rewritten in place, the host-side wait has reset the ring
     x.start(torch.full_like(term, -1.0))
