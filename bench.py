@@ -448,7 +448,7 @@ def run(args, compute_factory=None):
         # the RCCL all-gather cost the step less is MEASURED here, before the timed region, on the very job that
         # follows: a few untimed steps with each, the maximum over the ranks (so every rank sees the same two numbers
         # and takes the same decision); the peer copies stay unless the collective is clearly faster
-        n_cal = max(4, min(16, args.steps))
+        n_cal = max(8, min(16, args.steps))
         try:
             alt = D.AllGatherExchange(sh, 12, job.s0)
             t_p2p = timed_steps(job, cp, xch, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal

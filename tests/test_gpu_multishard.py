@@ -120,9 +120,13 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
     assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["rollouts_total"] == n_total and out["scaling"] == mode
     assert out["shards"] == [list(workloads.shard_egos(n_total, 2, r)) for r in range(2)]
     assert "bitwise" in out["exchange"].pop("verified_how")
-    assert out["exchange"] == {"kind": "peer_copies" if exchange in ("p2p", "auto") else "all_gather_into_tensor",
-                               "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4, "verified": True,
-                               "requested": exchange, "fallback_reason": None}
+    # `auto` MEASURES which exchange the timed region uses (exchange_calibration): whichever it chose must be what ran
+    kind = out["exchange_calibration"]["chosen"] if exchange == "auto" else \
+        ("peer_copies" if exchange == "p2p" else "all_gather_into_tensor")
+    why = out["exchange"].pop("fallback_reason")
+    assert (why is None) if (exchange != "auto" or kind == "peer_copies") else why.startswith("calibration:")
+    assert out["exchange"] == {"kind": kind, "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4,
+                               "verified": True, "requested": exchange}
     assert out["value"] > 0 and out["roofline"]["bound"] == "valu" and "cpu_baseline" not in out
     cal = out["exchange_calibration"]
     if exchange == "auto":      # measured before the timed region: peer copies against the all-gather, same on every rank
@@ -162,9 +166,12 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
     assert out["n_gpus"] == 1 and out["world_seen"] == 1 and out["rollouts_total"] == 65536
     assert out["dist_backend"] == "nccl"
     assert "bitwise" in out["exchange"].pop("verified_how")
-    assert out["exchange"] == {"kind": "all_gather_into_tensor" if exchange == "rccl" else "peer_copies",
-                               "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True,
-                               "requested": exchange, "fallback_reason": None}
+    kind = out["exchange_calibration"]["chosen"] if exchange == "auto" else \
+        ("all_gather_into_tensor" if exchange == "rccl" else "peer_copies")
+    why = out["exchange"].pop("fallback_reason")
+    assert (why is None) if (exchange != "auto" or kind == "peer_copies") else why.startswith("calibration:")
+    assert out["exchange"] == {"kind": kind, "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True,
+                               "requested": exchange}
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
     assert out["roofline"]["bound"] == "valu" and out["shards"] == [[0, 65536]]
     assert (out["exchange_calibration"] is not None) == (exchange == "auto")
