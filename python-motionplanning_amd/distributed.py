@@ -310,8 +310,9 @@ class PeerExchange:
         return out
 
     def close(self):
-        """Collective (a barrier before the buffers go): EVERY rank passes the barrier, also one that has nothing to
-        free -- the rank whose allocation failed in an agreed-failure path must not skip what its peers enter."""
+        """Collective (two barriers: before the mappings go, and before the buffers themselves do): EVERY rank passes
+        them, also one that has nothing to free -- the rank whose allocation failed in an agreed-failure path must not
+        skip what its peers enter."""
         if self._closed:
             return
         self._closed = True
@@ -322,10 +323,15 @@ class PeerExchange:
             err = e
         if dist.is_initialized() and self.sh.world > 1:
             dist.barrier(group=self.sh.group)   # nobody is still writing into a buffer about to go
-        for p in self._peers:
-            self.h.call("vdyn_xchg_close", self._C.c_void_p(p))
+        try:
+            for p in self._peers:
+                self.h.call("vdyn_xchg_close", self._C.c_void_p(p))
+        except Exception as e:                          # noqa: BLE001
+            err = err or e
         self._peers = []
         self.recv = None
+        if dist.is_initialized() and self.sh.world > 1:
+            dist.barrier(group=self.sh.group)   # every rank has unmapped its peers' buffers before any owner frees one
         if self._own is not None:
             self.h.call("vdyn_xchg_free", self._C.c_void_p(self._own))
         self._own = None
