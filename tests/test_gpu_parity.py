@@ -1145,8 +1145,8 @@ def test_heterogeneous_fleet_rollout(gpu_vm, pkg, oracle, workloads):
 
 
 def test_fleet_256_classes_fp64_shared_controls(gpu_vm, pkg, oracle, workloads):
-    """include/vdyn.h promises 1 <= V <= 256: 256 fp64 classes are 96 KiB of constants (48 doubles each: 29 vehicle
-    constants + the 19 coefficients of the class's tire fit), beyond the 64 KiB a kernel gets without opting in.
+    """include/vdyn.h promises 1 <= V <= 256: 256 fp64 classes are 92 KiB of constants (46 doubles each: 29 vehicle
+    constants + the 17 coefficients of the class's tire fit), beyond the 64 KiB a kernel gets without opting in.
     256 different shape factors also cycle the host's per-thread cache of fits (sixteen slots)."""
     VP = pkg.VehicleParameters
     classes = [VP(mf=950.0 + 2.0 * v, mr=850.0 + 1.0 * v, BFL=18.0 + 0.02 * v, CFL=1.3 + 0.002 * v) for v in range(256)]

@@ -12,7 +12,8 @@ evaluation in that precision against float64 / long double:
     python3 tools/fit_tire_w.py            # table for C = 1.5047 (the reference's), 1.3, 1.9, 2.0
 
 fp32 (one rounding per step, as the packed fma does): degree 7 5.5e-7, **degree 8 2.2e-7**, degree 9+ no better
-(rounding-limited).  fp64: degree 16 3e-14, **degree 18 2e-15**, degree 20+ no better.  The library's own
+(rounding-limited).  fp64: **degree 16 3e-14** (the library's since round 4: two fmas per wheel and stage less), degree 18
+2e-15 (rounds 2-3), degree 20+ no better; output committed as profiles/r04_tire_fit_degrees.txt.  The library's own
 coefficients for a given C come from `VehicleModel.tire_fit(C)` (`vdyn_tire_fit_f32 / _f64`)."""
 import numpy as np
 from numpy.polynomial import chebyshev as Ch
