@@ -41,6 +41,8 @@ BYTES_PER_STEP_PER_ROLLOUT = 8.0 + 96.0 / HORIZON
 FLOP_PER_STEP = 850.0
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                        # fp32 vector peak (= fp32 MFMA peak)
+EXIT_WATCHDOG = 86                              # a rank ended by its own watchdog (deadline, or a peer rank failed)
+METRIC, UNIT = "RK4 vehicle-steps/sec", "vehicle-steps/s"
 
 
 def parse(argv=None):
@@ -88,6 +90,20 @@ def parse(argv=None):
                          "it stands, with `sections_timed_out`")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each all-gather before the next launch (A/B of the overlap)")
+    ap.add_argument("--run-timeout-s", type=float, default=240.0,
+                    help="whole-run watchdog, armed in every rank right after argument parsing (before torch, HIP, the "
+                         "exchange set-up, the calibration and the timed region): past it rank 0 prints the line as it "
+                         "stands (`value: null` when the headline is not measured yet) with `timed_out_in: <stage>`, "
+                         f"every rank names its stage on stderr and ends with exit code {EXIT_WATCHDOG}")
+    ap.add_argument("--total-budget-s", type=float, default=570.0,
+                    help="N>1: wall-clock budget of the whole command, both attempts together (the launcher starts "
+                         "fresh ranks ONCE with --exchange rccl --no-calibration when the first set ends without a "
+                         "measured headline and the peer copies were in play); the second attempt's watchdog gets "
+                         "what is left of it")
+    ap.add_argument("--no-relaunch", action="store_true", help="N>1: one attempt only")
+    # set by the launcher for the second attempt: nothing touches the peer-copy exchange (auto -> rccl, `exchange_ab`
+    # skips p2p, `strong` runs over the all-gather)
+    ap.add_argument("--no-peer-copies", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -245,6 +261,250 @@ def spawn_ranks(n, argv, script=None, port=None):
     return subprocess.run(cmd, env=env).returncode
 
 
+class Watchdog:
+    """Whole-run watchdog of ONE rank (a daemon thread), armed before the rank imports torch or touches HIP.
+
+    It ends the rank -- rank 0 prints the line as it stands first -- when (a) the run deadline passes, (b) the
+    sections deadline passes (armed when the untimed sections after the headline begin), or (c) the abort file
+    appears: the launcher's per-rank supervisor creates it when ANY rank of this attempt ended non-zero, so that the
+    ranks still sitting in a collective with the dead one do not wait out their whole deadline.  The stage the main
+    thread was in goes into the line (`timed_out_in`) and, for every rank, onto stderr.  Exit code EXIT_WATCHDOG:
+    os._exit from the timer thread, because the main thread may be blocked inside a collective or a HIP call for good."""
+
+    def __init__(self, rank, out, run_timeout_s, abort_file=None, poll_s=0.25):
+        import threading
+        self.rank, self.out, self.abort_file, self.poll_s = rank, out, abort_file, poll_s
+        self.t0 = time.monotonic()
+        self.run_deadline = self.t0 + run_timeout_s if run_timeout_s and run_timeout_s > 0 else None
+        self.sections_deadline, self.sections_timeout_s = None, None
+        self.stage = "start"
+        self.printed = threading.Lock()
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, name="bench-watchdog", daemon=True)
+        self._thread.start()
+
+    def set_stage(self, name):
+        self.stage = name
+
+    def arm_sections(self, seconds):
+        self.sections_timeout_s = seconds
+        self.sections_deadline = time.monotonic() + seconds
+
+    def disarm_sections(self):
+        self.sections_deadline = None
+
+    def cancel(self):
+        self._stop.set()
+
+    def emit(self):
+        """Rank 0 prints the ONE line; whoever gets here first (main thread or watchdog) prints, the other does not."""
+        if self.printed.acquire(blocking=False) and self.rank == 0:
+            print(json.dumps(self.out), flush=True)
+
+    def _loop(self):
+        while not self._stop.wait(self.poll_s):
+            now = time.monotonic()
+            if self.abort_file and os.path.exists(self.abort_file):
+                self._bail("peer_rank_failed", now - self.t0)
+            if self.sections_deadline is not None and now > self.sections_deadline:
+                self._bail("sections_deadline", self.sections_timeout_s)
+            if self.run_deadline is not None and now > self.run_deadline:
+                self._bail("run_deadline", now - self.t0)
+
+    def _bail(self, why, after_s):
+        if self._stop.is_set():
+            return
+        stage = self.stage
+        sys.stderr.write(f"[bench.py] rank {self.rank}: watchdog ({why}) after {after_s:.1f} s in stage "
+                         f"'{stage}'; exit code {EXIT_WATCHDOG}\n")
+        sys.stderr.flush()
+        self.out["timed_out_in"] = stage
+        self.out["timed_out"] = {"why": why, "after_s": after_s, "exit_code": EXIT_WATCHDOG}
+        if self.out.get("value") is not None:       # the headline is measured: what hung is one of the sections
+            self.out["sections_timed_out"] = {"after_s": after_s, "in": stage, "why": why}
+        # (the main thread may be adding keys while this one dumps: retry rather than lose the line)
+        for _ in range(20):
+            try:
+                self.emit()
+                break
+            except RuntimeError:
+                self.printed.release()
+                time.sleep(0.05)
+        os._exit(EXIT_WATCHDOG)
+
+
+def _is_result_line(ln):
+    if not ln.startswith("{"):
+        return None
+    try:
+        d = json.loads(ln)
+    except ValueError:
+        return None
+    return d if isinstance(d, dict) and "metric" in d else None
+
+
+def supervise(args, argv, script):
+    """One rank's SUPERVISOR: what a rank process started by torch.distributed.run (the driver's launch line, or our
+    own `spawn_ranks`) becomes when WORLD_SIZE > 1.  It never imports torch and never touches HIP; the rank's real
+    work runs in a child process (`VDYN_BENCH_WORKER=1`, same RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+
+    Why: the peer-copy exchange has never run across devices where this was built.  If the first set of ranks ends
+    without a measured headline -- a rank's watchdog fired, a rank crashed -- and the peer copies were in play
+    (--exchange auto / p2p), every supervisor starts a FRESH child rank once with `--exchange rccl --no-calibration
+    --no-peer-copies` (the collective north_star names) on a new rendezvous port; the line then carries
+    `relaunched: {after, first_attempt_stage, ...}`.  Never a re-exec of a process that has initialised the GPU.
+
+    The supervisors of one node agree through small files in a per-launch directory under the temp dir (keyed by the
+    common parent -- the torchrun agent -- and MASTER_PORT): `aK.failed` (any rank of attempt K ended non-zero; the
+    workers' watchdogs poll it and end early) and `aK.decision`, written by rank 0's supervisor alone: it is the one
+    that sees whether a line with a value was printed.  Rank 0's supervisor holds the worker's JSON line back and is
+    the only process that prints one: exactly ONE line whatever happens (`value: null` and the stages if both attempts
+    failed).  Exit code 0 when a measured headline was printed."""
+    import subprocess
+    import tempfile
+    import threading
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    t_launch = float(os.environ.get("VDYN_BENCH_T0") or time.time())
+    cdir = os.path.join(tempfile.gettempdir(), f"vdyn_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+    os.makedirs(cdir, exist_ok=True)
+    grace = 15.0
+
+    def put(name, obj=None):
+        tmp = os.path.join(cdir, f".{name}.{rank}.tmp")
+        with open(tmp, "w") as f:
+            json.dump(obj if obj is not None else {"rank": rank}, f)
+        os.replace(tmp, os.path.join(cdir, name))
+
+    def get(name):
+        try:
+            with open(os.path.join(cdir, name)) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            return None
+
+    def attempt(k, child_argv, env_extra, timeout_s):
+        """Run this rank's worker of attempt k to its end (bounded).  -> (exit code, held result line or None)"""
+        env = dict(os.environ)
+        env.update({"VDYN_BENCH_WORKER": "1", "VDYN_BENCH_ATTEMPT": str(k),
+                    "VDYN_BENCH_ABORT_FILE": os.path.join(cdir, f"a{k}.failed")})
+        env.update(env_extra)                # a value of None removes the variable
+        cmd = [sys.executable, script, *child_argv]
+        proc = subprocess.Popen(cmd, env={a: b for a, b in env.items() if b is not None},
+                                stdout=subprocess.PIPE if rank == 0 else None, text=True if rank == 0 else None)
+        held = []
+
+        def pump():
+            for ln in proc.stdout:
+                d = _is_result_line(ln.strip())
+                if d is not None:
+                    held.append(d)          # the ONE line is printed by this supervisor, after the decision
+                else:
+                    sys.stdout.write(ln)
+                    sys.stdout.flush()
+
+        th = None
+        if rank == 0:
+            th = threading.Thread(target=pump, daemon=True)
+            th.start()
+        try:
+            rc = proc.wait(timeout=timeout_s + grace)
+        except subprocess.TimeoutExpired:
+            # its own watchdog did not end it (blocked where not even os._exit gets through, or stopped): kill it
+            sys.stderr.write(f"[bench.py] supervisor of rank {rank}: attempt {k} worker still alive "
+                             f"{timeout_s + grace:.0f} s after its start; killing it\n")
+            proc.kill()
+            try:
+                rc = proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                rc = -9                      # unkillable (uninterruptible in the driver): go on without it
+        if th is not None:
+            th.join(timeout=5)
+        if rc != 0:
+            put(f"a{k}.failed")
+        return rc, (held[-1] if held else None)
+
+    def wait_decision(k, limit_s):
+        t_end = time.monotonic() + limit_s
+        while time.monotonic() < t_end:
+            d = get(f"a{k}.decision")
+            if d is not None:
+                return d
+            time.sleep(0.1)
+        return None
+
+    def stub_line(why):
+        return {"metric": METRIC, "value": None, "unit": UNIT, "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "higher_is_better": True, "error": why}
+
+    # ---- attempt 1: the command as typed ------------------------------------------------------------------------
+    rc1, line1 = attempt(1, argv, {}, args.run_timeout_s)
+    can_relaunch = (not args.no_relaunch and not args.no_peer_copies and args.exchange in ("auto", "p2p"))
+    if rank == 0:
+        measured = line1 is not None and line1.get("value") is not None
+        if measured:
+            put("a1.decision", {"action": "done"})
+            if rc1 != 0:
+                line1["rank0_exit_code"] = rc1
+            print(json.dumps(line1), flush=True)
+            return 0
+        l1 = line1 or {}
+        first = {"after": rc1, "first_attempt_stage": l1.get("timed_out_in") or l1.get("failed_in"),
+                 "first_attempt_why": (l1.get("timed_out") or {}).get("why")
+                 or ("exception: " + l1["error"] if l1.get("error") else "rank 0 ended without a line"),
+                 "first_attempt_s": time.time() - t_launch}
+        left = args.total_budget_s - (time.time() - t_launch) - grace - 5.0
+        t2 = min(args.run_timeout_s, left)
+        if not can_relaunch or left < 30.0:
+            put("a1.decision", {"action": "give_up"})
+            line = line1 or stub_line(f"rank 0 ended with code {rc1} without a line")
+            line["relaunched"] = None
+            line["not_relaunched_because"] = ("--no-relaunch / the peer copies were not in play" if not can_relaunch
+                                              else f"{left:.0f} s of the budget left")
+            print(json.dumps(line), flush=True)
+            return rc1 or EXIT_WATCHDOG
+        port2 = free_port()
+        put("a1.decision", {"action": "relaunch", "port": port2, "run_timeout_s": t2})
+        dec = {"action": "relaunch", "port": port2, "run_timeout_s": t2}
+    else:
+        # rank 0's supervisor decides after ITS worker ended, which its watchdog bounds
+        dec = wait_decision(1, args.run_timeout_s + 2 * grace + 30.0)
+        if dec is None or dec["action"] == "give_up":
+            return rc1 or EXIT_WATCHDOG
+        if dec["action"] == "done":
+            return 0
+    # ---- attempt 2: fresh ranks, the collective north_star names, no peer copies anywhere -----------------------
+    argv2, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--exchange":
+            skip = True
+            continue
+        if a.startswith("--exchange=") or a in ("--no-calibration", "--no-peer-copies") or a.startswith("--run-timeout-s="):
+            continue
+        if a == "--run-timeout-s":
+            skip = True
+            continue
+        argv2.append(a)
+    argv2 += ["--exchange", "rccl", "--no-calibration", "--no-peer-copies", "--run-timeout-s", f"{dec['run_timeout_s']:.1f}"]
+    sys.stderr.write(f"[bench.py] supervisor of rank {rank}: first attempt ended with code {rc1} and no measured "
+                     f"headline; starting a fresh rank with --exchange rccl (port {dec['port']})\n")
+    # a rendezvous of its own: rank 0 of the new set hosts the store (the agent's store still holds the first set's keys)
+    rc2, line2 = attempt(2, argv2, {"MASTER_PORT": str(dec["port"]), "TORCHELASTIC_USE_AGENT_STORE": None},
+                         dec["run_timeout_s"])
+    if rank != 0:
+        # the outcome is rank 0's to report: a non-zero exit here would make the agent tear down rank 0's supervisor
+        # before it has printed the line
+        return 0
+    line = line2 or line1 or stub_line(f"rank 0 ended with codes {rc1}, {rc2} without a line")
+    first["second_attempt_exit_code"] = rc2
+    line["relaunched"] = first
+    print(json.dumps(line), flush=True)
+    return 0 if line.get("value") is not None else (rc2 or EXIT_WATCHDOG)
+
+
 def total_rollouts(world, per_gpu, strong):
     """Rollouts of the whole job.  One GPU: BASELINE configs[2] as named (65536 = 9362 egos x 7
     lattice paths + one ego with 2).  Strong scaling: the same 65536, split.  Weak scaling on
@@ -305,16 +565,40 @@ def run(args, compute_factory=None):
     the per-rank compute (default: HipCompute); tests/test_bench_multirank.py passes a CPU
     stand-in to rehearse THIS function's sharding, exchange, timing and JSON with gloo ranks."""
     import gc
-    import threading
     from types import SimpleNamespace
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # The whole-run watchdog comes FIRST: before torch is imported, before HIP, the process group, the exchange
+    # set-up (hipIpcOpenMemHandle on a peer device, the self-test push), the calibration and the timed region --
+    # none of which has ever run across devices where this was built.  `out` is the line; it is valid JSON of the
+    # contract's shape from here on (value null until the headline is measured).
+    out = {"metric": METRIC, "value": None, "unit": UNIT, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "attempt": int(os.environ.get("VDYN_BENCH_ATTEMPT", "1"))}
+    wd = Watchdog(rank, out, args.run_timeout_s, os.environ.get("VDYN_BENCH_ABORT_FILE"))
+    try:
+        return _run(args, compute_factory, wd, out, world, rank, local_rank)
+    except Exception as e:
+        # a rank that fails still leaves the line behind (rank 0), with the stage and the exception; the traceback
+        # goes to stderr as for any uncaught exception and the exit code is non-zero
+        out["error"], out["failed_in"] = repr(e), wd.stage
+        sys.stderr.write(f"[bench.py] rank {rank}: {e!r} in stage '{wd.stage}'\n")
+        wd.emit()
+        raise
+
+
+def _run(args, compute_factory, wd, out, world, rank, local_rank):
+    import gc
+    from types import SimpleNamespace
+    wd.set_stage("import torch")
+    import torch
+    import torch.distributed as dist
+    wd.set_stage("load the library, create the handle")
     pkg = importlib.import_module("python-motionplanning_amd")
     W = pkg.workloads
     D = importlib.import_module("python-motionplanning_amd.distributed")
@@ -329,7 +613,9 @@ def run(args, compute_factory=None):
     on_gpu = getattr(cp, "hip", False)
     dev = cp.device
     collective = world > 1 or args.force_collective
+    exchange_kind = "rccl" if args.no_peer_copies else args.exchange
     if collective:
+        wd.set_stage("init_process_group")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
@@ -438,37 +724,48 @@ def run(args, compute_factory=None):
                     "inputs (bitwise)")
 
     # ---- the headline measurement: what `value` is -------------------------------------------------------------
+    wd.set_stage("make_job")
     n_total = total_rollouts(world, per_gpu, args.strong)
     job = make_job(n_total)
     sh, n_local, tab = job.sh, job.n_local, job.tab
-    xch = D.make_exchange(args.exchange, sh, rows=12, like=job.s0, handle=cp.handle()) if collective else None
+    wd.set_stage(f"make_exchange({exchange_kind})")
+    xch = D.make_exchange(exchange_kind, sh, rows=12, like=job.s0, handle=cp.handle()) if collective else None
     calibration = None
-    if collective and args.exchange == "auto" and xch.kind == "peer_copies" and not args.no_calibration:
+    if collective and exchange_kind == "auto" and xch.kind == "peer_copies" and not args.no_calibration:
         # `auto`, second half: the peer copies have never run across devices where this was built, so whether they or
         # the RCCL all-gather cost the step less is MEASURED here, before the timed region, on the very job that
         # follows: a few untimed steps with each, the maximum over the ranks (so every rank sees the same two numbers
         # and takes the same decision); the peer copies stay unless the collective is clearly faster
         n_cal = max(8, min(16, args.steps))
-        try:
-            alt = D.AllGatherExchange(sh, 12, job.s0)
-            t_p2p = timed_steps(job, cp, xch, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
-            t_rccl = timed_steps(job, cp, alt, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
-            calibration = {"steps": n_cal, "peer_copies_ms_per_step": t_p2p * 1e3, "all_gather_ms_per_step": t_rccl * 1e3,
-                           "rule": "peer copies unless the all-gather is more than 3 % faster"}
-            if t_rccl < 0.97 * t_p2p:
-                xch.close()
-                xch, alt = alt, None
-                xch.fallback_reason = (f"calibration: all-gather {t_rccl * 1e3:.4f} ms per step against "
-                                       f"{t_p2p * 1e3:.4f} ms with peer copies")
-            else:
-                alt.close()
-        except Exception as e:                      # noqa: BLE001 -- the exchange already set up and tested stays
-            calibration = {"steps": n_cal, "error": repr(e)}
+        # No try / except around this block: its steps are collectives (the fence's barrier, the all-reduce of the
+        # elapsed time, PeerExchange.close's two barriers), and a rank that caught its own exception here would go on
+        # to the headline's collectives while its peers still sit in the calibration's.  A rank that fails here ENDS
+        # (non-zero, traceback on stderr); its supervisor marks the attempt failed, the other ranks' watchdogs end
+        # them, and the launcher starts fresh ranks with --exchange rccl --no-calibration (supervise()).
+        wd.set_stage("calibration: peer copies")
+        alt = D.AllGatherExchange(sh, 12, job.s0)
+        t_p2p = timed_steps(job, cp, xch, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
+        wd.set_stage("calibration: all-gather")
+        t_rccl = timed_steps(job, cp, alt, n_cal, 2, overlap=not args.no_overlap).elapsed / n_cal
+        calibration = {"steps": n_cal, "peer_copies_ms_per_step": t_p2p * 1e3, "all_gather_ms_per_step": t_rccl * 1e3,
+                       "rule": "peer copies unless the all-gather is more than 3 % faster"}
+        # t_p2p and t_rccl are maxima over the ranks (all-reduced in timed_steps): every rank takes the same branch
+        wd.set_stage("calibration: close the exchange not chosen")
+        if t_rccl < 0.97 * t_p2p:
+            xch.close()
+            xch, alt = alt, None
+            xch.fallback_reason = (f"calibration: all-gather {t_rccl * 1e3:.4f} ms per step against "
+                                   f"{t_p2p * 1e3:.4f} ms with peer copies")
+        else:
+            alt.close()
+            alt = None
         calibration["chosen"] = xch.kind
+    wd.set_stage("headline: warm-up and timed region")
     m = timed_steps(job, cp, xch, args.steps, args.warmup, overlap=not args.no_overlap, prewarm_ms=args.prewarm_ms)
     term, elapsed = m.term, m.elapsed
     gathered_ok = None
     if collective:
+        wd.set_stage("headline: verify the gathered result")
         gathered_ok, full = verify(job, cp, xch, term)
         if args.dump_gathered:
             np.save(os.path.join(args.dump_gathered, f"gathered_rank{rank}.npy"), full.cpu().numpy())
@@ -481,8 +778,8 @@ def run(args, compute_factory=None):
     kern_s = kern_iso if collective else m.region_s / args.steps
     units = n_total * H * args.steps
     steps_per_launch = n_local * H
-    out = {
-        "metric": "RK4 vehicle-steps/sec", "value": units / elapsed, "unit": "vehicle-steps/s",
+    head = {
+        "metric": METRIC, "value": units / elapsed, "unit": UNIT,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak",
@@ -500,7 +797,8 @@ def run(args, compute_factory=None):
         "exchange": None if not collective else {"kind": xch.kind, "overlapped": not args.no_overlap,
                                                  "bytes_per_rank": 12 * sh.n_pad * 4, "verified": gathered_ok,
                                                  "verified_how": VERIFIED_HOW,
-                                                 "requested": args.exchange, "fallback_reason": xch.fallback_reason},
+                                                 "requested": args.exchange, "fallback_reason": xch.fallback_reason,
+                                                 "peer_copies_disabled": bool(args.no_peer_copies)},
         "config": {
             "workload": f"BASELINE configs[2]: {per_gpu} rollouts per GPU (ego r//7, lattice path r%7; whole egos per "
                         f"rank: {n_total} in all) x {H} RK4 steps, dt=1e-3, fp32 Pacejka, per-path controls shared "
@@ -513,14 +811,14 @@ def run(args, compute_factory=None):
     }
     if rank == 0:
         build_id = pkg._lib.build_id() if on_gpu else None
-        out["build_id"] = build_id
+        head["build_id"] = build_id
         cf = counter_fields(pmc_summary() if on_gpu else {}, build_id, steps_per_launch, kern_s,
                             rollouts=n_local if H == HORIZON else -1)
         # the binding roofline of this kernel is VALU issue, priced as 850 flop per
         # vehicle-step against the fp32 vector peak
         tf = FLOP_PER_STEP * steps_per_launch / kern_s / 1e12
         algo_bytes = BYTES_PER_STEP_SHARED * steps_per_launch + tab.nbytes + 4 * n_local
-        out["roofline"] = {
+        head["roofline"] = {
             "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "per_gpu": True,
             "flop_per_vehicle_step": FLOP_PER_STEP, "kernel": "rollout_kernel<float,2,LDS-shared>",
@@ -533,59 +831,43 @@ def run(args, compute_factory=None):
                     "carries 0.48 B per vehicle-step (roofline_hbm); VALU issue binds",
         }
         if args.dump_durations:
-            out["roofline"]["kernel_ms_all"] = [round(float(x) * 1e3, 4) for x in durs]
-        out["roofline"].update(cf)
+            head["roofline"]["kernel_ms_all"] = [round(float(x) * 1e3, 4) for x in durs]
+        head["roofline"].update(cf)
         ach = algo_bytes / kern_s / 1e9
-        out["roofline_hbm"] = {
+        head["roofline_hbm"] = {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": cf.get("traffic"), "per_gpu": True,
             "algorithmic_bytes_per_launch": algo_bytes,
         }
+
+    out.update(head)        # the headline is in the line from here on (the watchdog prints `out`)
 
     # ---- everything below is OUTSIDE the timed region and only adds keys to the line ---------------------------
     # One `python bench.py --gpus N` is all an 8-GPU lease gets, so the default N > 1 line also carries what
     # north_star and SURVEY 8(d) config 4 ask for: both exchanges side by side, the fixed-65536 split, the CPU
     # baseline.  The headline line is complete at this point: should one of the sections below hang (a rank lost
     # inside a collective), a watchdog prints the line as it stands -- with `sections_timed_out` -- and ends the rank.
-    printed = threading.Lock()
-
-    def emit():
-        if printed.acquire(blocking=False) and rank == 0:
-            print(json.dumps(out), flush=True)
-
-    def bail():
-        # (timer thread; the main thread may be adding keys: retry the dump rather than lose the line)
-        out["sections_timed_out"] = {"after_s": args.sections_timeout_s, "in": out.pop("_section", None)}
-        for _ in range(20):
-            try:
-                emit()
-                break
-            except RuntimeError:
-                printed.release()
-                time.sleep(0.05)
-        os._exit(0)
-
-    watchdog = None
     if collective and not args.no_sections:
-        watchdog = threading.Timer(args.sections_timeout_s, bail)
-        watchdog.daemon = True
-        watchdog.start()
+        wd.arm_sections(args.sections_timeout_s)
 
     strong_full = None
     if collective and not args.no_sections:
         # the fixed-N split below uses what the headline used (after `auto`'s calibration, that may be the collective)
-        strong_exchange = "rccl" if args.exchange == "auto" and xch.kind != "peer_copies" else args.exchange
+        strong_exchange = "rccl" if exchange_kind == "auto" and xch.kind != "peer_copies" else exchange_kind
+        wd.set_stage("close the headline's exchange")
         xch.close()
         xch = None
         k_ab, w_ab = max(1, args.steps // 2), max(1, args.warmup // 2)
         # (a) the two exchanges, K/2 steps each on the headline's job: the collective north_star names (RCCL
         # all_gather_into_tensor) and the peer copies, fresh objects in the same ranks
-        out["_section"] = "exchange_ab"
         ab = {"steps": k_ab, "warmup": w_ab, "no_exchange_kernel_ms": kern_iso * 1e3}
         for kind in ("rccl", "p2p"):
+            wd.set_stage(f"exchange_ab: {kind}")
             try:
                 if kind == "rccl":
                     x, why = D.AllGatherExchange(sh, 12, job.s0), None
+                elif args.no_peer_copies:
+                    x, why = None, "peer copies disabled for this attempt (--no-peer-copies: the first set of ranks ended without a headline)"
                 elif cp.handle() is None:
                     x, why = None, "no library handle (CPU stand-in)"
                 else:
@@ -604,7 +886,7 @@ def run(args, compute_factory=None):
         out["exchange_ab"] = ab
         # (b) BASELINE configs[3] as worded: the FIXED 65536 rollouts split over the ranks by whole egos, lane kernel
         # (bitwise the single-GPU result) and wheel-parallel kernel (the labelled second number for small shards)
-        out["_section"] = "strong"
+        wd.set_stage("strong")
         n_s = total_rollouts(world, per_gpu, True)
         st = {"rollouts_total": n_s, "steps": k_ab, "warmup": w_ab, "verified_how": VERIFIED_HOW,
               "note": "fixed-N split: one GPU already runs 65536 rollouts at one wave per SIMD, so the lane kernel's "
@@ -614,6 +896,7 @@ def run(args, compute_factory=None):
             job_s = job if n_s == n_total else make_job(n_s)
             st["shards"] = [list(b) for b in job_s.sh.bounds]
             for name, lanes_s in (("lane", 1), ("wheel_parallel", 4)):
+                wd.set_stage(f"strong: {name}")
                 cpx = cp if lanes_s == lanes else cp.with_lanes(lanes_s)
                 x = D.make_exchange(strong_exchange, job_s.sh, rows=12, like=job_s.s0, handle=cpx.handle())
                 r = timed_steps(job_s, cpx, x, k_ab, w_ab)
@@ -628,16 +911,16 @@ def run(args, compute_factory=None):
         except Exception as e:                          # noqa: BLE001
             st["error"] = repr(e)
         out["strong"] = st
-        out.pop("_section", None)
 
     if rank == 0:
         if world == 1 and on_gpu and not args.no_extra and not args.strong:
+            wd.set_stage("extra")
             out["extra"] = extra_configs(cp.vm, W, torch, dev, job.s0, tab, job.pid)
         if not args.no_cpu_baseline and (on_gpu or world > 1):
             # rank 0's host, the other ranks idle at the barrier below.  BASELINE's second metric, the fp32 state
             # error against the fp64 oracle, needs the full configs[2] result: the headline's own terminal states on
             # one GPU, the gathered fixed-65536 split (bitwise the same thing) on more
-            out["_section"] = "cpu_baseline"
+            wd.set_stage("cpu_baseline")
             full_size = per_gpu == N_PER_GPU and H == HORIZON
             gpu_term = term_c = None
             if full_size and world == 1 and not args.strong:
@@ -653,20 +936,26 @@ def run(args, compute_factory=None):
                 out["fp32_state_error"] = err
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["value"] / cb["value"]
-            out.pop("_section", None)
-    if watchdog is not None:
-        watchdog.cancel()
-    emit()
+    wd.disarm_sections()
+    wd.set_stage("print the line")
+    wd.emit()
     if collective:
+        # (still under the whole-run watchdog: the line is out; a rank lost here ends the others with EXIT_WATCHDOG)
+        wd.set_stage("closing barrier")
         dist.barrier()
         if xch is not None:
             xch.close()
         dist.destroy_process_group()
+    wd.cancel()
     return out
 
 
-def main():
-    args = parse()
+def main(argv=None, compute_factory=None, script=None):
+    """`script` / `compute_factory`: tests/_bench_gloo_entry.py runs this very function with the oracle as the
+    per-rank compute; its ranks are re-started (supervise) through that script, not through bench.py."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    script = script or os.path.abspath(__file__)
     # Host waits poll the completion signal instead of sleeping on an interrupt (ROCr reads this when it starts, so
     # it is set before anything imports torch or touches HIP, and the launcher's children inherit it).  A 0.15 ms
     # step is short against an interrupt wake-up: K = 20, W = 5 gives 0.1554 instead of 0.1572 ms per step with it,
@@ -676,10 +965,14 @@ def main():
     # dmabuf IPC (the only mode the host driver supports) for RCCL and hipIpc*MemHandle: ROCr reads this at start-up
     # too, so it is set here for BOTH launch forms (torchrun-started ranks and our own children), not after HIP is up
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("VDYN_BENCH_T0", repr(time.time()))      # when the command started: both attempts share a budget
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # typed as `python3 bench.py --gpus N`: become the launcher (nothing below has touched HIP)
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
-    run(args)
+        sys.exit(spawn_ranks(args.gpus, argv, script=script))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("VDYN_BENCH_WORKER") != "1":
+        # a rank as torch.distributed.run starts it (the driver's launch line or spawn_ranks): supervise a child rank
+        sys.exit(supervise(args, argv, script))
+    run(args, compute_factory)
 
 
 def extra_configs(vm, W, torch, dev, s0, tab, pid):

@@ -14,7 +14,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRY = os.path.join(REPO, "tests", "_bench_gloo_entry.py")
 
 
-def _launch(tmp_path, world, extra, env_extra=None, cpu_baseline=False):
+def _launch(tmp_path, world, extra, env_extra=None, cpu_baseline=False, want_rc=0):
     argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-extra",
             "--horizon", "12", "--dump-gathered", str(tmp_path), *extra]
     if not cpu_baseline:
@@ -24,10 +24,12 @@ def _launch(tmp_path, world, extra, env_extra=None, cpu_baseline=False):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(env_extra or {})
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert res.returncode == 0, res.stderr[-3000:]
+    assert res.returncode == want_rc, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, f"rank 0 prints ONE JSON line, got {len(lines)}"
-    return json.loads(lines[0])
+    assert len(lines) == 1, f"rank 0 prints ONE JSON line, got {len(lines)}: {res.stdout[-2000:]} {res.stderr[-2000:]}"
+    out = json.loads(lines[0])
+    out["_stderr"] = res.stderr
+    return out
 
 
 @pytest.mark.parametrize("mode,per_gpu", [("weak", 70), ("strong", 65), ("strong", 70)])
@@ -92,6 +94,73 @@ def test_default_multirank_line_carries_the_cpu_baseline(tmp_path):
 def test_sections_can_be_switched_off(tmp_path):
     out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--no-sections"])
     assert "exchange_ab" not in out and "strong" not in out and out["exchange"]["verified"] is True
+
+
+FAKE_P2P = {"VDYN_TEST_FAKE_P2P": "1"}
+
+
+def test_auto_with_peer_copies_calibrates_and_stays_collective(tmp_path):
+    """`auto` with a (stand-in) peer-copy exchange available: the calibration runs, both numbers are maxima over the
+    ranks, the choice is the same on every rank (the run would hang otherwise), nothing is relaunched."""
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--run-timeout-s", "200"], env_extra=FAKE_P2P)
+    cal = out["exchange_calibration"]
+    assert cal["steps"] >= 8 and cal["peer_copies_ms_per_step"] > 0 and cal["all_gather_ms_per_step"] > 0
+    assert cal["chosen"] == out["exchange"]["kind"] and "error" not in cal
+    assert out["exchange"]["verified"] is True and "relaunched" not in out and out["attempt"] == 1
+    assert out["exchange_ab"]["p2p"]["available"] and out["exchange_ab"]["p2p"]["verified"] is True
+
+
+def test_peer_copy_that_never_completes_ends_in_a_relaunch_with_rccl_and_one_line(tmp_path):
+    """the stand-in PeerExchange.start blocks forever on every rank.  Each rank's whole-run
+    watchdog (armed before torch is imported) ends it with EXIT_WATCHDOG, rank 0 having printed a `value: null` line
+    that names the stage; the supervisors then start FRESH ranks once with --exchange rccl --no-calibration
+    --no-peer-copies; ONE line comes out, measured, marked `relaunched`, exit code 0."""
+    import bench
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--run-timeout-s", "25"],
+                  env_extra=dict(FAKE_P2P, VDYN_TEST_P2P_FAULT="hang_in_start"))
+    rl = out["relaunched"]
+    assert rl["after"] == bench.EXIT_WATCHDOG and rl["first_attempt_stage"] == "calibration: peer copies"
+    # (the rank whose deadline passes first ends, its supervisor marks the attempt failed, the other rank may see that
+    # mark a moment before its own deadline)
+    assert rl["first_attempt_why"] in ("run_deadline", "peer_rank_failed") and rl["second_attempt_exit_code"] == 0
+    assert out["attempt"] == 2 and out["value"] > 0 and out["exchange"]["verified"] is True
+    assert out["exchange"]["kind"] == "all_gather_into_tensor" and out["exchange"]["peer_copies_disabled"] is True
+    assert out["exchange_calibration"] is None
+    assert out["exchange_ab"]["p2p"]["available"] is False and "disabled" in out["exchange_ab"]["p2p"]["reason"]
+    assert out["strong"]["lane"]["verified"] is True and out["strong"]["lane"]["exchange"] == "all_gather_into_tensor"
+    # every rank said on stderr where it was
+    assert "watchdog (run_deadline)" in out["_stderr"]
+    for r in (0, 1):
+        assert f"[bench.py] rank {r}: watchdog (" in out["_stderr"]
+
+
+def test_rank_that_raises_after_the_agree_step_ends_in_a_relaunch_without_waiting_out_the_deadline(tmp_path):
+    """Rank 1 raises in try_create after the agree step (its peers have gone on to the next collective).  It ends
+    non-zero; its supervisor marks the attempt failed; rank 0's watchdog sees the mark and ends rank 0 long before its
+    200 s deadline; fresh ranks run over RCCL."""
+    import time
+    t0 = time.time()
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--run-timeout-s", "200"],
+                  env_extra=dict(FAKE_P2P, VDYN_TEST_P2P_FAULT="raise_after_agree"))
+    assert time.time() - t0 < 150, "the surviving rank must not wait out its deadline"
+    rl = out["relaunched"]
+    # rank 0 either saw the mark (a rank hung in an RCCL collective would) or its gloo collective raised when rank 1's
+    # sockets closed: both leave a line with the stage behind
+    assert rl["first_attempt_why"] == "peer_rank_failed" or rl["first_attempt_why"].startswith("exception: ")
+    assert rl["first_attempt_stage"] is not None and rl["after"] != 0
+    assert out["value"] > 0 and out["attempt"] == 2 and out["exchange"]["kind"] == "all_gather_into_tensor"
+    assert out["exchange"]["verified"] is True
+    assert "stand-in failure after the agree step" in out["_stderr"]
+
+
+def test_no_relaunch_when_the_collective_itself_was_asked_for(tmp_path):
+    """--exchange rccl and a hang: there is nothing else to fall back to; still ONE line (value null, the stage), and
+    a non-zero exit code."""
+    import bench
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--run-timeout-s", "20", "--exchange", "rccl"],
+                  env_extra={"VDYN_TEST_HANG_STAGE": "headline"}, want_rc=1)
+    assert out["value"] is None and out["relaunched"] is None and out["timed_out_in"].startswith("headline")
+    assert out["timed_out"]["exit_code"] == bench.EXIT_WATCHDOG
 
 
 def test_total_rollouts_keeps_one_wave_per_simd():
