@@ -1184,6 +1184,40 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
         vm.rollout(s0_h, tab, path_id=pid_h)
     t = (time.perf_counter() - t0) / 5
     ex["host_abi_pcie_inclusive_f32"] = {"steps_per_s": n / t, "ms": t * 1e3}
+    # ... and where the host ABI hurts: PER-ROLLOUT controls [200][2][65536] fp32 = 105 MB handed over as pageable
+    # NumPy memory (what a caller of the reference holds).  The library stages them in horizon chunks -- worker threads
+    # copy chunk c + 1 into pinned memory while chunk c crosses PCIe and chunk c - 1 is integrated
+    # (rollout_host_pipelined, vdyn_capi.hip).  Beside it the floor: the same 105 MB from PINNED memory to the device
+    # in one hipMemcpyAsync, measured here on this box.
+    ctrl_h = W.expand_shared_controls(tab, pid_h)
+    vm.rollout(s0_h, ctrl_h)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        vm.rollout(s0_h, ctrl_h)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    pin = torch.from_numpy(ctrl_h).pin_memory()
+    dst = torch.empty(ctrl_h.shape, dtype=torch.float32, device=dev)
+    dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a_, b_ in ev:
+        a_.record()
+        dst.copy_(pin, non_blocking=True)
+        b_.record()
+    torch.cuda.synchronize()
+    t_pin = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev])) * 1e-3
+    t0 = time.perf_counter()
+    np.copyto(np.empty_like(ctrl_h), ctrl_h)
+    t_memcpy = time.perf_counter() - t0
+    ex["host_abi_per_rollout_controls_f32"] = {
+        "steps_per_s": n / t, "ms": t * 1e3, "ms_min": float(min(ts)) * 1e3, "controls_MB": ctrl_h.nbytes / 1e6,
+        "pinned_h2d_ms": t_pin * 1e3, "pinned_h2d_GBs": ctrl_h.nbytes / t_pin / 1e9,
+        "ratio_to_pinned_h2d": t / t_pin, "one_thread_memcpy_ms": t_memcpy * 1e3,
+        "copy_threads": os.environ.get("VDYN_COPY_THREADS", "default: min(8, usable CPUs / 2)"),
+        "bar": "<= 1.3 x the pinned one-shot upload of the same bytes (VERDICT round 4, item 4)"}
+    del pin, dst, ctrl_h
     # two independent batches in flight: launches alternate between two HIP streams (one handle each),
     # so the next batch's dispatch, table staging and first loads overlap the tail of the previous one
     # and the two waves a SIMD then holds run out of phase (tools/two_stream_probe.py)

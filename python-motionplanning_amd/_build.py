@@ -79,7 +79,10 @@ def is_stale():
     # alone miss.  The hash covers every source, header and flag: a file that is merely NEWER than the library (a
     # checkout, a copy onto the GPU box) with the same content is not a reason to compile for four minutes.
     built, extra = _read_id()
-    return built is None or built != source_hash(extra)
+    # a library built once with extra flags (a diagnostic -D, phase timers) is never "fresh" for a plain build() / load():
+    # tests and bench would run a non-default build silently (its id says so -- source_hash covers the flags -- but
+    # nothing would rebuild it)
+    return built is None or bool(extra) or built != source_hash(())
 
 
 def _content_hash(paths):

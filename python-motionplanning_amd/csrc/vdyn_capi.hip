@@ -1,14 +1,145 @@
 // vdyn_capi.hip -- the C ABI of include/vdyn.h: handle, argument checks, the
 // `_dev` entry points (enqueue on the caller's stream) and the `_host` entry
 // points (stage through pinned + device scratch owned by the handle).
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "vdyn_internal.hpp"
+
+// Host copies of the _host entry points (caller's pageable memory <-> the handle's pinned staging buffer).  One thread
+// moves 8-12 GB/s; the PCIe link behind it moves several times that, so a large staging copy -- 105 MB of per-rollout
+// controls at BASELINE configs[2] -- is spread over a few worker threads that do nothing else (no HIP call is ever made
+// from them).  The calling thread takes slices too; copies under kParallelBytes stay a plain memcpy.
+class CopyPool {
+public:
+    static constexpr size_t kParallelBytes = 1u << 20, kSliceBytes = 512u << 10;
+
+    // CPUs this process may run on: the affinity mask, capped by the cgroup quota (a one-GPU share of a big host)
+    static int usable_cpus()
+    {
+        int n = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+        std::ifstream f("/sys/fs/cgroup/cpu.max");
+        std::string quota;
+        long long period = 0;
+        if (f >> quota >> period && quota != "max" && period > 0) {
+            const long long q = std::atoll(quota.c_str());
+            if (q > 0) n = std::min<long long>(n, std::max<long long>(1, q / period));
+        }
+        return n;
+    }
+    static int default_threads()
+    {
+        if (const char *e = std::getenv("VDYN_COPY_THREADS")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= 64) return v;
+        }
+        return std::min(8, std::max(1, usable_cpus() / 2));
+    }
+
+    explicit CopyPool(int threads) : nthreads_(std::max(1, threads))
+    {
+        for (int i = 1; i < nthreads_; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    int threads() const { return nthreads_; }
+
+    // dst <- src, blocking.  One job at a time (the handle is single-threaded by contract).
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        if (bytes == 0) return;
+        if (bytes < kParallelBytes || nthreads_ == 1) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        const size_t slices = (bytes + kSliceBytes - 1) / kSliceBytes;
+        {
+            // the job's fields change only while no worker is inside work() (a worker woken late for a job that is
+            // already complete still reads them once): workers enter and leave work() under this mutex's count
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [this] { return active_ == 0; });
+            dst_ = static_cast<char *>(dst);
+            src_ = static_cast<const char *>(src);
+            bytes_ = bytes;
+            slices_ = slices;
+            next_.store(0, std::memory_order_relaxed);
+            left_ = slices;
+            ++generation_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return left_ == 0; });
+    }
+
+private:
+    void work()
+    {
+        size_t mine = 0;
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= slices_) break;
+            const size_t off = i * kSliceBytes;
+            std::memcpy(dst_ + off, src_ + off, std::min(kSliceBytes, bytes_ - off));
+            ++mine;
+        }
+        if (mine) {
+            std::lock_guard<std::mutex> lk(m_);
+            left_ -= mine;
+            if (left_ == 0) done_.notify_all();
+        }
+    }
+    void run()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                ++active_;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--active_ == 0) done_.notify_all();
+            }
+        }
+    }
+    const int nthreads_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    bool stop_ = false;
+    unsigned long long generation_ = 0;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0, slices_ = 0, left_ = 0;
+    int active_ = 0;            // workers inside work()
+    std::atomic<size_t> next_{0};
+};
 
 struct VdynHandle {
     int device = 0;
@@ -37,6 +168,19 @@ struct VdynHandle {
     int push_streams = 0;           // copy streams in use (0: no push issued since the last vdyn_xchg_wait)
     void *h_mapped = nullptr;       // small host-coherent buffer the GPU reads / writes in place
     void *d_mapped = nullptr;       // its device address
+    // _host entry points: worker threads of the staging copies (created with the first large copy), the upload stream
+    // of the pipelined rollout and its events (rollout_host_pipelined)
+    CopyPool *pool = nullptr;
+    hipStream_t stage_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {}, ev_kernel[2] = {};
+
+    void host_copy(void *dst, const void *src, size_t bytes)
+    {
+        if (bytes == 0) return;         // (an optional buffer the caller left out: null pointer, zero bytes)
+        if (bytes >= CopyPool::kParallelBytes && !pool) pool = new (std::nothrow) CopyPool(CopyPool::default_threads());
+        if (pool) pool->copy(dst, src, bytes);
+        else std::memcpy(dst, src, bytes);
+    }
 
     int fail(int code, const std::string &msg)
     {
@@ -186,6 +330,12 @@ void vdyn_destroy(VdynHandle *h)
         if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
     }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    if (h->stage_stream) { (void)hipStreamSynchronize(h->stage_stream); (void)hipStreamDestroy(h->stage_stream); }
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_h2d[i]) (void)hipEventDestroy(h->ev_h2d[i]);
+        if (h->ev_kernel[i]) (void)hipEventDestroy(h->ev_kernel[i]);
+    }
+    delete h->pool;
     delete h;
 }
 
@@ -517,6 +667,30 @@ int mpc_dev(VdynHandle *h, int E, int C, int H, const T *ego, const T *cand, con
     return VDYN_OK;
 }
 
+// the handle's device scratch and pinned staging buffer, grown on demand (contents are not kept)
+static int ensure_scratch(VdynHandle *h, size_t dev_bytes, size_t pinned_bytes)
+{
+    if (dev_bytes > h->d_bytes) {
+        if (h->d_scratch) { (void)hipFree(h->d_scratch); h->d_scratch = nullptr; h->d_bytes = 0; }
+        if (hipMalloc(&h->d_scratch, dev_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_scratch = nullptr;
+            return h->fail(VDYN_ERR_OOM, "device scratch allocation failed");
+        }
+        h->d_bytes = dev_bytes;
+    }
+    if (pinned_bytes > h->h_bytes) {
+        if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; h->h_bytes = 0; }
+        if (hipHostMalloc(&h->h_pinned, pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->h_pinned = nullptr;
+            return h->fail(VDYN_ERR_OOM, "pinned staging allocation failed");
+        }
+        h->h_bytes = pinned_bytes;
+    }
+    return VDYN_OK;
+}
+
 // ---- host staging: [inputs | outputs] packed in one pinned buffer and one device
 // buffer, so a call costs one H2D copy, the kernel, one D2H copy.
 class Stage {
@@ -551,23 +725,13 @@ public:
             }
             host_ = (char *)h_->h_mapped;
             dev_ = (char *)h_->d_mapped;
-            for (auto &r : ins_) std::memcpy(host_ + r.off, r.ptr, r.bytes);
+            for (auto &r : ins_) h_->host_copy(host_ + r.off, r.ptr, r.bytes);
             return VDYN_OK;
         }
-        if (total_ > h_->d_bytes) {
-            if (h_->d_scratch) { (void)hipFree(h_->d_scratch); h_->d_scratch = nullptr; h_->d_bytes = 0; }
-            if (hipMalloc(&h_->d_scratch, total_) != hipSuccess) return h_->fail(VDYN_ERR_OOM, "device scratch allocation failed");
-            h_->d_bytes = total_;
-        }
-        if (total_ > h_->h_bytes) {
-            if (h_->h_pinned) { (void)hipHostFree(h_->h_pinned); h_->h_pinned = nullptr; h_->h_bytes = 0; }
-            if (hipHostMalloc(&h_->h_pinned, total_, hipHostMallocDefault) != hipSuccess)
-                return h_->fail(VDYN_ERR_OOM, "pinned staging allocation failed");
-            h_->h_bytes = total_;
-        }
+        if (int rc = ensure_scratch(h_, total_, total_)) return rc;
         host_ = (char *)h_->h_pinned;
         dev_ = (char *)h_->d_scratch;
-        for (auto &r : ins_) std::memcpy(host_ + r.off, r.ptr, r.bytes);
+        for (auto &r : ins_) h_->host_copy(host_ + r.off, r.ptr, r.bytes);
         if (in_end_ > 0)
             VDYN_HIP(h_, hipMemcpyAsync(dev_, host_, in_end_, hipMemcpyHostToDevice, h_->stream));
         return VDYN_OK;
@@ -584,7 +748,7 @@ public:
                                         h_->stream));
         VDYN_HIP(h_, hipStreamSynchronize(h_->stream));
         for (auto &r : outs_)
-            if (r.ptr) std::memcpy(r.ptr, host_ + r.off, r.bytes);
+            if (r.ptr) h_->host_copy(r.ptr, host_ + r.off, r.bytes);
         return VDYN_OK;
     }
 
@@ -653,6 +817,95 @@ int planar_model_host(VdynHandle *h, int64_t n, const T *state, const T *ctrl12,
     return s.download();
 }
 
+// Per-rollout controls [H][k][n] from host memory are the one _host input that is LARGE (105 MB at BASELINE configs[2],
+// against 3 MB of states): staged whole -- memcpy into pinned memory, one H2D copy, the kernel -- the call costs the sum
+// of the three.  Here the horizon is cut into chunks of whole steps (a chunk of [H][k][n] is one contiguous slab) that
+// flow through two pinned and two device buffers: while the worker threads copy chunk c + 1 into pinned memory, chunk c
+// crosses PCIe on the upload stream and the kernel integrates chunk c - 1 on the compute stream, handing the state on
+// device to device (two state buffers, alternating).  What makes this exact is the kernels' split-horizon identity:
+// rollout(a) then rollout(b) from its terminal state IS rollout(a + b), bit for bit, trajectory rows included when the
+// cut is a multiple of traj_stride (tests/test_gpu_parity.py holds every kernel to it), so the host ABI still returns
+// what the device ABI returns for the same inputs.
+//   pinned: [state0 | terminal | ctrl 0 | ctrl 1 | traj]      device: [state A | state B | ctrl 0 | ctrl 1 | traj]
+static constexpr size_t kPipelineMinBytes = 8u << 20;      // below this the whole-buffer staging is as fast
+
+template <typename T>
+int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
+{
+    const size_t e = sizeof(T) * (size_t)a.n, rows = (size_t)h->state_rows;
+    const size_t step_bytes = (size_t)a.k * e, ctrl_bytes = (size_t)a.H * step_bytes;
+    // chunk: about an eighth of the horizon's bytes, 4 .. 32 MB, whole steps, a multiple of traj_stride
+    const size_t want = std::min<size_t>(std::max<size_t>(ctrl_bytes / 8, 4u << 20), 32u << 20);
+    int64_t hc = std::max<int64_t>(1, (int64_t)(want / step_bytes));
+    if (a.traj) hc = std::max<int64_t>(a.traj_stride, hc / a.traj_stride * a.traj_stride);
+    hc = std::min<int64_t>(hc, a.H);
+    const size_t chunk_bytes = (size_t)hc * step_bytes;
+    const size_t traj_bytes = a.traj ? (size_t)(a.H / a.traj_stride) * 12 * e : 0;
+    auto r256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t st = r256(rows * e), cb = r256(chunk_bytes);
+    if (int rc = ensure_scratch(h, 2 * st + 2 * cb + r256(traj_bytes), 2 * st + 2 * cb + r256(traj_bytes))) return rc;
+    VDYN_HIP(h, hipSetDevice(h->device));
+    if (!h->stage_stream) VDYN_HIP(h, hipStreamCreateWithFlags(&h->stage_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->ev_h2d[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
+        if (!h->ev_kernel[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_kernel[i], hipEventDisableTiming));
+    }
+    char *pin = static_cast<char *>(h->h_pinned), *dev = static_cast<char *>(h->d_scratch);
+    char *pin_state = pin, *pin_term = pin + st, *pin_ctrl[2] = {pin + 2 * st, pin + 2 * st + cb}, *pin_traj = pin + 2 * st + 2 * cb;
+    T *dev_state[2] = {reinterpret_cast<T *>(dev), reinterpret_cast<T *>(dev + st)};
+    char *dev_ctrl[2] = {dev + 2 * st, dev + 2 * st + cb};
+    T *dev_traj = a.traj ? reinterpret_cast<T *>(dev + 2 * st + 2 * cb) : nullptr;
+
+    // On any failure past this point copies may be in flight from / into the staging buffers: drain both streams
+    // before the error goes back (the buffers belong to the handle and the next call reuses them).
+    auto drain = [&](int rc) {
+        (void)hipStreamSynchronize(h->stage_stream);
+        (void)hipStreamSynchronize(h->stream);
+        return rc;
+    };
+#define VDYN_PIPE(expr)                                                     \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) return drain(h->fail_hip(#expr, e_));         \
+    } while (0)
+
+    h->host_copy(pin_state, a.state0, rows * e);
+    VDYN_PIPE(hipMemcpyAsync(dev_state[0], pin_state, rows * e, hipMemcpyHostToDevice, h->stage_stream));
+    const char *src = reinterpret_cast<const char *>(a.ctrl);
+    int64_t t0 = 0, traj_row = 0;
+    int c = 0;
+    for (; t0 < a.H; t0 += hc, ++c) {
+        const int b = c & 1;
+        const int64_t hn = std::min<int64_t>(hc, a.H - t0);
+        const size_t bytes = (size_t)hn * step_bytes;
+        // pinned ctrl[b] was the source of chunk c - 2's upload: that copy must have run before the host overwrites it
+        if (c >= 2) VDYN_PIPE(hipEventSynchronize(h->ev_h2d[b]));
+        h->host_copy(pin_ctrl[b], src + (size_t)t0 * step_bytes, bytes);
+        // device ctrl[b] is what chunk c - 2's kernel reads: the upload stream waits for that kernel, on the device
+        if (c >= 2) VDYN_PIPE(hipStreamWaitEvent(h->stage_stream, h->ev_kernel[b], 0));
+        VDYN_PIPE(hipMemcpyAsync(dev_ctrl[b], pin_ctrl[b], bytes, hipMemcpyHostToDevice, h->stage_stream));
+        VDYN_PIPE(hipEventRecord(h->ev_h2d[b], h->stage_stream));
+        // (the upload stream is in order: chunk 0's event also covers the state upload queued before it)
+        VDYN_PIPE(hipStreamWaitEvent(h->stream, h->ev_h2d[b], 0));
+        vdyn::RolloutArgs<T> ac = a;
+        ac.H = (int)hn;
+        ac.state0 = dev_state[b];
+        ac.terminal = dev_state[b ^ 1];
+        ac.ctrl = reinterpret_cast<const T *>(dev_ctrl[b]);
+        ac.traj = a.traj ? dev_traj + (size_t)traj_row * 12 * (size_t)a.n : nullptr;
+        if (int rc = rollout_dev<T>(h, ac, h->stream, who)) return drain(rc);
+        VDYN_PIPE(hipEventRecord(h->ev_kernel[b], h->stream));
+        if (a.traj) traj_row += hn / a.traj_stride;
+    }
+    VDYN_PIPE(hipMemcpyAsync(pin_term, dev_state[c & 1], rows * e, hipMemcpyDeviceToHost, h->stream));
+    if (a.traj && traj_bytes) VDYN_PIPE(hipMemcpyAsync(pin_traj, dev_traj, traj_bytes, hipMemcpyDeviceToHost, h->stream));
+    VDYN_PIPE(hipStreamSynchronize(h->stream));
+#undef VDYN_PIPE
+    h->host_copy(a.terminal, pin_term, rows * e);
+    if (a.traj && traj_bytes) h->host_copy(a.traj, pin_traj, traj_bytes);
+    return VDYN_OK;
+}
+
 template <typename T>
 int rollout_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
 {
@@ -668,6 +921,10 @@ int rollout_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
     const size_t ctrl_bytes = a.layout == VDYN_CTRL_PER_ROLLOUT
                                   ? (size_t)a.H * a.k * e
                                   : sizeof(T) * (size_t)a.P * a.H * a.k;
+    if (a.layout == VDYN_CTRL_PER_ROLLOUT && a.H >= 2 && ctrl_bytes >= kPipelineMinBytes && !a.state_dot && !a.outputs &&
+        (!a.traj || a.traj_stride <= a.H / 2) && std::isfinite(a.dt) &&
+        !(h->state_rows != 12 && sizeof(T) != 4) && !(a.traj && !row_writer_fits<T>(a.n, 12)))
+        return rollout_host_pipelined<T>(h, a, who);
     Stage s(h);
     const size_t rows = (size_t)h->state_rows;
     const size_t i0 = s.in(a.state0, rows * e), i1 = s.in(a.ctrl, ctrl_bytes),

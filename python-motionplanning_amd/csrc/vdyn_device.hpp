@@ -622,8 +622,14 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 }
 
 // One step for one lane: the FAST path, then SAFE for the lanes that need it.
-// The outer test is wave-uniform (one scalar branch, normally not taken); the
-// inner one restricts the redo to the lanes that asked for it.
+// The test is wave-uniform (one scalar branch, normally not taken).  Behind it EVERY lane of the wave runs the SAFE
+// step under the full exec mask and each value is then SELECTED per lane (a lane that stayed in range keeps its FAST
+// result bit for bit).  Until round 5 the redo sat in a divergent region, `if (!ok) { SAFE }`, which costs a wave
+// exactly as much -- and whose join block is where this compiler (ROCm 7.2's LLVM) can place register-allocator
+// copies of loop-carried values IN FRONT of the exec restore, i.e. under the redo's partial mask: lanes that did not
+// take the redo then keep the previous step's value (x, y parked in AGPRs: round 4's "RowReader" miscompare, and the
+// shipped fp64 k = 12 shared-table general-chain instance; tools/isa/exec_restore_audit.py).
+// A uniform branch has no exec mask to restore, so its join cannot be hit.
 __device__ __forceinline__ float atan_lib(float x) { return ::atanf(x); }
 __device__ __forceinline__ double atan_lib(double x) { return ::atan(x); }
 
@@ -636,17 +642,33 @@ __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &a
     const bool ok = rk4_step<T, K2, DIAG, false, CS, PRE, FITSRC>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot,
                                                                 outputs, sd0, cd0);
     if (Math<T, false>::kHasRangeLimit) {
+#ifdef VDYN_MASKED_REDO             // diagnostic build only (tools/isa/reader_all.hip): the divergent form, for the reproducer
         if (__builtin_expect(__any(!ok) != 0, 0)) {
-            if (!ok) {
-                if (PRE == 2) {     // delta[0] is the tangent of the (front) steering angle
-                    const T a = atan_lib(delta[0]);
-                    const T dl[4] = {a, a, T(0), T(0)};
-                    rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, dl, tq, mu, h, sn, axn, ayn, state_dot, outputs);
-                } else {
-                    rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
-                }
+            if (!ok) rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
+        }
+#else
+        if (__builtin_expect(__any(!ok) != 0, 0)) {
+            T sr[10], axr, ayr, sdr[10];
+            Outputs18<T> outr;
+            T dl[4] = {delta[0], delta[1], delta[2], delta[3]};
+            if (PRE == 2) {         // delta[0] is the tangent of the (front) steering angle
+                dl[0] = dl[1] = atan_lib(delta[0]);
+                dl[2] = dl[3] = T(0);
+            }
+            rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, dl, tq, mu, h, sr, axr, ayr, DIAG ? sdr : nullptr,
+                                            DIAG ? &outr : nullptr);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) sn[i] = ok ? sn[i] : sr[i];
+            axn = ok ? axn : axr;
+            ayn = ok ? ayn : ayr;
+            if (DIAG) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) state_dot[i] = ok ? state_dot[i] : sdr[i];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) outputs->v[i] = ok ? outputs->v[i] : outr.v[i];
             }
         }
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 10; ++i) s[i] = sn[i];

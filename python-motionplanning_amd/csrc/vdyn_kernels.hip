@@ -332,7 +332,11 @@ rollout_kernel(DevParams<T> P, int64_t n, int H, const T *__restrict__ state0,
         Ctrl<T, K> c;
         fetch(c, 0);
         int tc = 0;
+#ifdef VDYN_READER_ALL          // diagnostic build only (tools/isa/reader_all.hip): the reader for every k and precision
+        if constexpr (LAYOUT == 0 && !DIAG && !TRAJ) {
+#else
         if constexpr (LAYOUT == 0 && K == 2 && sizeof(T) == 4 && !DIAG && !TRAJ) {
+#endif
             // per-rollout controls: rows read strictly in order through a running wave-uniform base (RowReader); the
             // trip's last load is row tc + 4, so the loop stops while that row exists and the one-step loop below
             // finishes the horizon.  k = 2 only: with k = 12 the twelve scalar row offsets do not fit the scalar file

@@ -91,19 +91,12 @@ def _row_rel(got, want):
 SWEEP_POOL = {}
 
 
-@pytest.mark.parametrize("seed,every,H", SWEEP_CASES)
-def test_fp32_closed_loop_seed_sweep(gpu_vm, oracle, workloads, seed, every, H):
-    """The fp32 closed loop against the fp64 oracle on six more seeds, update periods 1 / 7 / 10 / 25 and horizons up to
-    400 (stanley_controller.py:56-129 every `every` sub-steps, drive.py:128-138), 8192 vehicles each -- and beside it
-    the plain-C FLOAT oracle on the same inputs, which is what makes "the outliers are the precision's, not the
-    kernel's" checkable:
-      * fp64 kernel: target indices exactly the oracle's, terminal states within 1e-9;
-      * fp32 kernel: every vehicle whose target indices ALL equal the fp64 oracle's ends within north_star's 1e-3
-        (row-relative) of the fp64 oracle;
-      * every fp32 vehicle beyond 1e-3 has at least one controller update with another target index than the oracle's
-        (the law is discontinuous in the index: that, not the step arithmetic, is what moved it);
-      * the share of fp32-kernel vehicles beyond 1e-3 is at most twice the share the float oracle itself puts beyond
-        1e-3 of the fp64 oracle (+ 3 vehicles of counting noise per case; the pooled test below has no such slack)."""
+def _sweep_case(gpu_vm, oracle, workloads, seed, every, H):
+    """One case of the sweep (test_fp32_closed_loop_seed_sweep's docstring says what is asserted); its counts go into
+    SWEEP_POOL and its line into SWEEP_TABLE.  Run once per session: the pooled test calls it for whatever case the
+    session has not run yet, so it never depends on which tests were selected."""
+    if (seed, every, H) in SWEEP_POOL:
+        return
     n, dt = SWEEP_N, 1e-3
     st, cs, wp, wc, pid = workloads.closed_loop_config(n, dtype=np.float64, seed=seed)
     f32 = [a.astype(np.float32) for a in (st, cs, wp)]
@@ -146,12 +139,30 @@ def test_fp32_closed_loop_seed_sweep(gpu_vm, oracle, workloads, seed, every, H):
     assert np.abs(log32[:, 12] - olog[:, 12])[:, same_k].max() <= 2e-3    # filtered steering command, same-index vehicles
 
 
-def test_fp32_closed_loop_seed_sweep_pooled():
+@pytest.mark.parametrize("seed,every,H", SWEEP_CASES)
+def test_fp32_closed_loop_seed_sweep(gpu_vm, oracle, workloads, seed, every, H):
+    """The fp32 closed loop against the fp64 oracle on six more seeds, update periods 1 / 7 / 10 / 25 and horizons up to
+    400 (stanley_controller.py:56-129 every `every` sub-steps, drive.py:128-138), 8192 vehicles each -- and beside it
+    the plain-C FLOAT oracle on the same inputs, which is what makes "the outliers are the precision's, not the
+    kernel's" checkable:
+      * fp64 kernel: target indices exactly the oracle's, terminal states within 1e-9;
+      * fp32 kernel: every vehicle whose target indices ALL equal the fp64 oracle's ends within north_star's 1e-3
+        (row-relative) of the fp64 oracle;
+      * every fp32 vehicle beyond 1e-3 has at least one controller update with another target index than the oracle's
+        (the law is discontinuous in the index: that, not the step arithmetic, is what moved it);
+      * the share of fp32-kernel vehicles beyond 1e-3 is at most twice the share the float oracle itself puts beyond
+        1e-3 of the fp64 oracle (+ 3 vehicles of counting noise per case; the pooled test below has no such slack)."""
+    _sweep_case(gpu_vm, oracle, workloads, seed, every, H)
+
+
+def test_fp32_closed_loop_seed_sweep_pooled(gpu_vm, oracle, workloads):
     """Over the six cases together (49152 vehicles): the kernel's outlier count against the float oracle's, factor 2, no
-    additive slack; the table goes to gpurun_out/ (committed copy: profiles/r04_closed_loop_seed_sweep.txt)."""
+    additive slack; the table goes to gpurun_out/ (committed copy: profiles/r04_closed_loop_seed_sweep.txt).  Cases the
+    session has not run (a `-k` selection) are computed here: this test never passes by skipping."""
     import os
-    if len(SWEEP_POOL) != len(SWEEP_CASES):
-        pytest.skip("needs the six sweep cases in the same session")
+    for case in SWEEP_CASES:
+        _sweep_case(gpu_vm, oracle, workloads, *case)
+    assert len(SWEEP_POOL) == len(SWEEP_CASES)
     k, f, sk, sf, n = (sum(v[i] for v in SWEEP_POOL.values()) for i in range(5))
     tail = (f"pooled over {n} vehicles: fp32 kernel {k} beyond 1e-3 ({sk} with a differing index), "
             f"plain-C float oracle {f} beyond 1e-3 ({sf} with a differing index); bar: kernel <= 2 x float oracle")

@@ -186,3 +186,50 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
     assert st["lane"]["lanes_per_rollout"] == 1 and st["wheel_parallel"]["lanes_per_rollout"] == 4
     assert 0 < out["roofline_hbm"]["frac"] < 1 and out["roofline_hbm"]["per_gpu"] is True
     assert "sections_timed_out" not in out
+
+
+def test_seven_destinations_per_push_through_seven_copy_streams(gpu_vm, pkg):
+    """The push of an EIGHT-rank job (n_dst = 7: one hipMemcpyAsync per peer, each on its own copy stream behind one
+    event) had never executed in any form -- the one-GPU box admits six GPU processes.  Here the seven destinations are
+    seven slot buffers of the same process (what differs from a real peer is only how the pointer was obtained): sixteen
+    pushes back to back from the compute stream, a device-side fence every fourth, sources overwritten as soon as the
+    fence allows -- the steady state of distributed.PeerExchange.start -- then the last block must be the one in every
+    slot, and the host time per push (the 8 us-per-peer projection of DESIGN.md section 6) is printed."""
+    import ctypes as C
+    import time
+    import torch
+    L = pkg._lib
+    vm = gpu_vm(1e-3)
+    h = vm.handle()
+    dev = torch.device("cuda:0")
+    world, rank, rows, n_pad = 8, 3, 12, 8192
+    block = rows * n_pad * 4
+    own, ipc = [C.c_void_p() for _ in range(world)], [L.VdynIpcHandle() for _ in range(world)]
+    for r in range(world):
+        h.call("vdyn_xchg_alloc", world * block, C.byref(own[r]), C.byref(ipc[r]))
+    dst = (C.c_void_p * 7)(*[own[r].value for r in range(world) if r != rank])
+    try:
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ring = [torch.empty((rows, n_pad), dtype=torch.float32, device=dev) for _ in range(8)]   # 2 * HOLD sources
+        torch.cuda.synchronize()
+        t_host = 0.0
+        for i in range(16):
+            if i >= 8 and i % 4 == 0:
+                h.call("vdyn_xchg_fence", stream)            # the four oldest sources may be rewritten behind it
+            src = ring[i % 8]
+            src.fill_(float(i + 1))                          # on the compute stream, ahead of the push
+            t0 = time.perf_counter()
+            h.call("vdyn_xchg_push", dst, 7, rank * block, C.c_void_p(src.data_ptr()), block, stream)
+            t_host += time.perf_counter() - t0
+        h.call("vdyn_xchg_wait")
+        torch.cuda.synchronize()
+        for r in range(world):
+            if r == rank:
+                continue
+            slots = torch.as_tensor(pkg.distributed._DeviceBuffer(own[r].value, (world, rows * n_pad), "<f4"), device=dev)
+            assert bool((slots[rank] == 16.0).all()), f"slot {rank} of buffer {r} does not hold the last block"
+        print(f"\n  n_dst = 7: host time per push {t_host / 16 * 1e6:.1f} us ({t_host / 16 / 7 * 1e6:.1f} us per destination)")
+    finally:
+        h.call("vdyn_xchg_wait")
+        for r in range(world):
+            h.call("vdyn_xchg_free", own[r])

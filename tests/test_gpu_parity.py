@@ -195,6 +195,52 @@ def test_config3_full_fp32_vs_oracle_and_properties(gpu_vm, oracle, workloads):
     assert np.array_equal(vm.rollout(s0[:, :4099], tab, path_id=pid[:4099]), term_h[:, :4099])
 
 
+@pytest.mark.parametrize("dtype,k,n,H", [(np.float32, 2, 16384, 70), (np.float32, 12, 4100, 50),
+                                         (np.float64, 2, 9000, 61), (np.float64, 12, 4096, 31)])
+def test_host_abi_pipelined_per_rollout_controls_equal_the_device_abi_bitwise(gpu_vm, dtype, k, n, H):
+    """Per-rollout controls handed over as HOST memory (NumPy arrays: the form a caller of the reference has) are staged
+    in horizon chunks -- chunk c + 1 copied into pinned memory by worker threads while chunk c crosses PCIe and chunk
+    c - 1 is integrated, the state handed on device to device (rollout_host_pipelined, vdyn_capi.hip; each case here
+    has more than 8 MB of controls, the threshold).  The result must be the device ABI's, bit for bit: terminal states,
+    trajectories at strides that do and do not divide the chunk, the compensated 22-row state, the wheel-parallel
+    kernel, ragged n."""
+    import torch
+    rng = np.random.default_rng(n + H)
+    s0 = np.zeros((12, n), dtype)
+    s0[0] = rng.uniform(10, 30, n)
+    s0[1], s0[2] = rng.normal(0, 0.2, n), rng.normal(0, 0.1, n)
+    s0[3:7] = s0[0] / 0.308309813617345 * rng.uniform(0.99, 1.01, (4, n))
+    s0[7] = rng.uniform(-np.pi, np.pi, n)
+    s0[8:10] = rng.uniform(0, 100, (2, n))
+    steer = rng.uniform(-0.3, 0.3, (H, 1, n))
+    if k == 2:
+        c = np.concatenate([steer, rng.uniform(-200, 400, (H, 1, n))], axis=1).astype(dtype)
+    else:
+        c = np.concatenate([steer, steer, np.zeros((H, 2, n)), rng.uniform(-200, 400, (H, 4, n)),
+                            rng.uniform(0.7, 1.0, (H, 4, n))], axis=1).astype(dtype)
+    assert c.nbytes > 8 << 20
+    dev = torch.device("cuda:0")
+    s0d, cd = torch.from_numpy(s0).to(dev), torch.from_numpy(c).to(dev)
+    for lanes in (1, 4):
+        vm = gpu_vm(1e-3, lanes_per_rollout=lanes)
+        want = vm.rollout(s0d, cd).cpu().numpy()
+        got = vm.rollout(s0, c)
+        assert isinstance(got, np.ndarray) and np.array_equal(got, want), f"lanes {lanes}: terminal"
+        assert np.array_equal(vm.rollout(s0, c), want), "second call (staging buffers reused)"
+        for stride in (1, 7, H // 2):
+            wt, wtraj = (x.cpu().numpy() for x in vm.rollout(s0d, cd, traj_stride=stride))
+            gt, gtraj = vm.rollout(s0, c, traj_stride=stride)
+            assert np.array_equal(gt, wt) and np.array_equal(gtraj, wtraj), f"lanes {lanes}, traj_stride {stride}"
+    vm = gpu_vm(1e-3)
+    if dtype == np.float32:                                           # compensated state sum: [22][n]
+        s22 = np.concatenate([s0, np.zeros((10, n), dtype)])
+        want = vm.rollout(torch.from_numpy(s22).to(dev), cd).cpu().numpy()
+        assert want.shape == (22, n) and np.array_equal(vm.rollout(s22, c), want)
+    # a short horizon / a small batch stays on the whole-buffer staging; same answer
+    assert np.array_equal(vm.rollout(s0[:, :100], np.ascontiguousarray(c[:, :, :100])),
+                          vm.rollout(s0d[:, :100].contiguous(), cd[:, :, :100].contiguous()).cpu().numpy())
+
+
 def test_fp32_long_horizon_1000_steps(gpu_vm, oracle, workloads):
     """fp32 rounding grows with the horizon (the state accumulation at |x| ~ 100 m rounds at 4e-6 per step):
     a 1000-step rollout (1 s) of 4096 config-3 rollouts against the fp64 oracle, row-relative and element-wise."""
@@ -355,6 +401,58 @@ def test_per_rollout_controls_with_safe_redo_lanes(gpu_vm, oracle, k):
         assert parity(tr, wtraj, tol, f"{np.dtype(dtype).name} k = {k}, shared table, trajectory, SAFE lanes") <= bar
         assert parity(t, wterm, tol) <= bar
         assert np.array_equal(vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid), t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 12])
+def test_general_chain_with_safe_redo_lanes(gpu_vm, oracle, pkg, k):
+    """The same detour on a handle whose tire fit is refused (C = 3.1: beyond what the fitted chain covers), i.e. the
+    kernels' CS = false instances -- the general atan -> sine chain.  Round 5's ISA audit (tools/isa/
+    exec_restore_audit.py) flagged the SHIPPED fp64 k = 12 shared-table instance of exactly this family for the
+    code-generation hazard behind round 4's RowReader miscompare: register-allocator copies of the loop-carried x, y
+    placed in front of the exec restore at the join of `if (!ok) { SAFE }`, so that lanes which did NOT take the redo
+    kept the previous step's x, y whenever a neighbour in their wave did.  No test reached that instance with SAFE
+    lanes before.  Since round 5 the redo runs under the full exec mask with a select per value (rk4_advance)."""
+    rng = np.random.default_rng(40 + k)
+    n, H, dt = 640, 23, 1e-3
+    veh = pkg.VehicleParameters()
+    for w in ("FL", "FR", "RL", "RR"):
+        setattr(veh, "C" + w, 3.1)
+    s0 = np.zeros((12, n))
+    s0[0] = rng.uniform(12, 30, n)
+    s0[1], s0[2] = rng.normal(0, 0.5, n), rng.normal(0, 0.3, n)
+    s0[3:7] = s0[0] / 0.308309813617345 * rng.uniform(0.97, 1.03, (4, n))
+    s0[7] = rng.uniform(-np.pi, np.pi, n)
+    s0[8:10] = rng.uniform(-400, 400, (2, n))
+    steer = rng.uniform(-0.3, 0.3, (H, n))
+    steer[:, ::3] = rng.uniform(0.8, 0.9, (H, (n + 2) // 3)) * rng.choice([-1, 1], (H, (n + 2) // 3))   # SAFE lanes
+    if k == 2:
+        c = np.stack([steer, rng.uniform(-300, 600, (H, n))], axis=1)
+    else:
+        c = np.concatenate([np.stack([steer, steer, 0.05 * steer, -0.05 * steer], axis=1),
+                            rng.uniform(-300, 600, (H, 4, n)), rng.uniform(0.6, 1.1, (H, 4, n))], axis=1)
+    vm = gpu_vm(dt, params=veh)
+    p = oracle.params_from(veh)
+    want, wtraj = oracle.rollout(p, s0, c, dt, traj_stride=1)
+    assert np.isfinite(want).all()
+    assert parity(vm.rollout(s0, c), want, F64_TOL, f"fp64 k = {k}, general chain, SAFE lanes") <= 1e-9
+    assert parity(vm.rollout(s0.astype(np.float32), c.astype(np.float32)), want, 1e-3, f"fp32 k = {k}, general chain") <= 1e-3
+    t64, traj64 = vm.rollout(s0, c, traj_stride=1)
+    assert parity(traj64, wtraj, F64_TOL, f"fp64 k = {k}, general chain, trajectory") <= 1e-9 and parity(t64, want, F64_TOL) <= 1e-9
+    # the controls as a table shared through LDS (nine paths, three of them beyond pi/4): the flagged instance
+    P = 9
+    tab = np.ascontiguousarray(np.transpose(c[:, :, :P], (2, 0, 1)))            # [P][H][k]
+    pid = (np.arange(n) % P).astype(np.int32)
+    wterm, wtraj = oracle.rollout(p, s0, tab, dt, path_id=pid, traj_stride=1)
+    for dtype, tol, bar in ((np.float64, F64_TOL, 1e-9), (np.float32, 1e-3, 1e-3)):
+        got = vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid)
+        assert parity(got, wterm, tol, f"{np.dtype(dtype).name} k = {k}, general chain, shared table, SAFE lanes") <= bar
+        t, tr = vm.rollout(s0.astype(dtype), tab.astype(dtype), path_id=pid, traj_stride=1)
+        assert parity(tr, wtraj, tol, f"{np.dtype(dtype).name} k = {k}, general chain, shared table, trajectory") <= bar
+        assert np.array_equal(t, got)
+    # wheel-parallel kernel (whole quads redo together)
+    vq = gpu_vm(dt, params=veh, lanes_per_rollout=4)
+    assert parity(vq.rollout(s0, c), want, F64_TOL, f"fp64 k = {k}, general chain, wheel-parallel, SAFE quads") <= 1e-9
 
 
 def test_permutation_invariance_and_ragged_sizes(gpu_vm, workloads):
