@@ -67,7 +67,7 @@ def parse(argv=None):
                          "IPC-mapped slot on copy streams: no CU-resident copy kernel) or the RCCL all-gather.  auto "
                          "(default) = peer copies when every rank can set them up and a test exchange arrives intact "
                          "on every rank, RCCL otherwise: with one rank the all-gather's copy kernel costs the rollout "
-                         "7.5 %% of its step, the copies 3.4 %% (profiles/r03_exchange_one_rank.json)")
+                         "7.5 %% of its step, the copies 3.4 %% (profiles/archive/r03_exchange_one_rank.json)")
     # rehearsal of the N > 1 path where only one GPU exists (tests/test_gpu_multishard.py): ranks share the listed
     # devices ("0,0": both on GPU 0), torch.distributed runs on gloo (RCCL refuses two ranks on one GPU)
     ap.add_argument("--device-map", default=None, help=argparse.SUPPRESS)

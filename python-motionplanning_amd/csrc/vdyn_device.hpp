@@ -46,7 +46,15 @@ namespace vdyn {
 // general chain); the wheel-parallel kernel keeps its lane's own wheel's column in registers either way.
 // A handle whose fits fail their check takes the general atan -> sine chain (lane_cs).
 constexpr int kTireFitDeg = 8;
-constexpr int kTireFitDeg64 = 16;
+// Degree of the fp64 fit: 16 (2.3e-14 at the reference's C, at most 3.9e-14 for any accepted C: profiles/
+// r05_tire_fit_by_C.txt; the soak test's thousandfold amplifiers then sit at 2e-11 against their 1e-10 bar, a margin of
+// five).  -DVDYN_TIRE_FIT_DEG64=18 (an even degree <= 22) builds round 3's fit -- 1.3e-15, two more fmas per wheel and
+// stage, vdyn_tire_fit_f64 then fills 19 coefficients -- should that bar ever be tightened.
+#ifndef VDYN_TIRE_FIT_DEG64
+#define VDYN_TIRE_FIT_DEG64 16
+#endif
+constexpr int kTireFitDeg64 = VDYN_TIRE_FIT_DEG64;
+static_assert(kTireFitDeg64 >= 12 && kTireFitDeg64 <= 22 && kTireFitDeg64 % 2 == 0, "fp64 tire fit degree");
 template <typename T> struct TireFit;
 template <> struct TireFit<float> {
     float W[kTireFitDeg + 1][4];

@@ -1673,7 +1673,7 @@ static bool fit_tire_wheel(double C, T *W, double tol)
     }
     return true;
 }
-constexpr double kTireFitTol32 = 5e-7, kTireFitTol64 = 5e-14;       // degree 8 / degree 16 (tools/fit_tire_w.py)
+constexpr double kTireFitTol32 = 5e-7, kTireFitTol64 = kTireFitDeg64 >= 18 ? 4e-15 : 5e-14;   // degree 8 / 16 (18: round 3's gate)
 
 // Both fits of one shape factor.
 struct TireFitC {

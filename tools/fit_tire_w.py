@@ -47,7 +47,26 @@ def errors(C, deg, dtype):
     return float(np.max(np.abs(G - want) * xl)), float(np.max((np.abs(G - want) / np.abs(want))[small]))
 
 
+def by_c():
+    """The library's degrees (fp32: 8, fp64: 16) over the whole range of shape factors a handle's fit is accepted for
+    (0 .. 2.9; gates 5e-7 / 5e-14, csrc/vdyn_kernels.hip kTireFitTol*): python3 tools/fit_tire_w.py --by-c
+    (committed as profiles/r05_tire_fit_by_C.txt; ADVICE round 4: the margin per C, not only at the reference's C)."""
+    cs = np.round(np.arange(0.05, 2.951, 0.05), 2)
+    for dtype, deg, gate in ((np.float32, 8, 5e-7), (np.float64, 16, 5e-14)):
+        rows = [(C,) + errors(float(C), deg, dtype) for C in cs]
+        worst = max(rows, key=lambda r: max(r[1], r[2]))
+        print(f"{np.dtype(dtype).name}, degree {deg}, gate {gate:g}: C  |error of sin(C atan x)|  relative error of sin(C atan x)/x (x <= sqrt 3)")
+        for C, a, r in rows:
+            print(f"  {C:4.2f}  {a:.2e}  {r:.2e}" + ("   <-- over the gate: such a handle keeps the general chain" if max(a, r) > gate else ""))
+        print(f"  worst: C = {worst[0]:.2f}: {max(worst[1], worst[2]):.2e} = {max(worst[1], worst[2]) / gate:.2f} of the gate; "
+              f"the reference's C = 1.5047: {max(errors(1.5047, deg, dtype)):.2e}")
+
+
 if __name__ == "__main__":
+    import sys
+    if "--by-c" in sys.argv:
+        by_c()
+        sys.exit(0)
     for dtype, degs in ((np.float32, (5, 6, 7, 8, 9, 10)), (np.float64, (12, 14, 16, 18, 20, 22))):
         print(f"{np.dtype(dtype).name}: max |error of sin(C atan x)| / max relative error of sin(C atan x)/x for x <= sqrt(3)")
         for C in (1.5047, 1.3, 1.9, 2.0):
