@@ -90,9 +90,10 @@ def parse(argv=None):
                          "it stands, with `sections_timed_out`")
     ap.add_argument("--no-overlap", action="store_true",
                     help="wait for each all-gather before the next launch (A/B of the overlap)")
-    ap.add_argument("--run-timeout-s", type=float, default=240.0,
+    ap.add_argument("--run-timeout-s", type=float, default=210.0,
                     help="whole-run watchdog, armed in every rank right after argument parsing (before torch, HIP, the "
-                         "exchange set-up, the calibration and the timed region): past it rank 0 prints the line as it "
+                         "exchange set-up, the calibration and the timed region; `import torch` has an allowance of its "
+                         "own, 180 s, and this clock starts when it returns): past it rank 0 prints the line as it "
                          "stands (`value: null` when the headline is not measured yet) with `timed_out_in: <stage>`, "
                          f"every rank names its stage on stderr and ends with exit code {EXIT_WATCHDOG}")
     ap.add_argument("--total-budget-s", type=float, default=570.0,
@@ -271,11 +272,15 @@ class Watchdog:
     thread was in goes into the line (`timed_out_in`) and, for every rank, onto stderr.  Exit code EXIT_WATCHDOG:
     os._exit from the timer thread, because the main thread may be blocked inside a collective or a HIP call for good."""
 
+    IMPORT_ALLOWANCE_S = 180.0      # the first `import torch` on a fresh box pages the image in: 1-2 minutes, not a hang
+
     def __init__(self, rank, out, run_timeout_s, abort_file=None, poll_s=0.25):
         import threading
         self.rank, self.out, self.abort_file, self.poll_s = rank, out, abort_file, poll_s
         self.t0 = time.monotonic()
-        self.run_deadline = self.t0 + run_timeout_s if run_timeout_s and run_timeout_s > 0 else None
+        self.run_timeout_s = run_timeout_s if run_timeout_s and run_timeout_s > 0 else None
+        # until torch is imported the deadline is the import allowance; restart_run_clock() then starts the run's own
+        self.run_deadline = self.t0 + self.IMPORT_ALLOWANCE_S if self.run_timeout_s else None
         self.sections_deadline, self.sections_timeout_s = None, None
         self.stage = "start"
         self.printed = threading.Lock()
@@ -285,6 +290,11 @@ class Watchdog:
 
     def set_stage(self, name):
         self.stage = name
+
+    def restart_run_clock(self):
+        """torch is imported: --run-timeout-s counts from here (the import had its own allowance)."""
+        if self.run_timeout_s:
+            self.run_deadline = time.monotonic() + self.run_timeout_s
 
     def arm_sections(self, seconds):
         self.sections_timeout_s = seconds
@@ -408,11 +418,11 @@ def supervise(args, argv, script):
             th = threading.Thread(target=pump, daemon=True)
             th.start()
         try:
-            rc = proc.wait(timeout=timeout_s + grace)
+            rc = proc.wait(timeout=timeout_s + Watchdog.IMPORT_ALLOWANCE_S + grace)
         except subprocess.TimeoutExpired:
             # its own watchdog did not end it (blocked where not even os._exit gets through, or stopped): kill it
             sys.stderr.write(f"[bench.py] supervisor of rank {rank}: attempt {k} worker still alive "
-                             f"{timeout_s + grace:.0f} s after its start; killing it\n")
+                             f"{timeout_s + Watchdog.IMPORT_ALLOWANCE_S + grace:.0f} s after its start; killing it\n")
             proc.kill()
             try:
                 rc = proc.wait(timeout=10)
@@ -468,7 +478,7 @@ def supervise(args, argv, script):
         dec = {"action": "relaunch", "port": port2, "run_timeout_s": t2}
     else:
         # rank 0's supervisor decides after ITS worker ended, which its watchdog bounds
-        dec = wait_decision(1, args.run_timeout_s + 2 * grace + 30.0)
+        dec = wait_decision(1, args.run_timeout_s + Watchdog.IMPORT_ALLOWANCE_S + 2 * grace + 30.0)
         if dec is None or dec["action"] == "give_up":
             return rc1 or EXIT_WATCHDOG
         if dec["action"] == "done":
@@ -598,6 +608,7 @@ def _run(args, compute_factory, wd, out, world, rank, local_rank):
     wd.set_stage("import torch")
     import torch
     import torch.distributed as dist
+    wd.restart_run_clock()
     wd.set_stage("load the library, create the handle")
     pkg = importlib.import_module("python-motionplanning_amd")
     W = pkg.workloads

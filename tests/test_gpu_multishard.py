@@ -126,7 +126,8 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path, gpu_vm, workloads, mode
     why = out["exchange"].pop("fallback_reason")
     assert (why is None) if (exchange != "auto" or kind == "peer_copies") else why.startswith("calibration:")
     assert out["exchange"] == {"kind": kind, "overlapped": True, "bytes_per_rank": 12 * (out["shards"][0][1]) * 4,
-                               "verified": True, "requested": exchange}
+                               "verified": True, "requested": exchange, "peer_copies_disabled": False}
+    assert out["attempt"] == 1 and "relaunched" not in out and "timed_out_in" not in out
     assert out["value"] > 0 and out["roofline"]["bound"] == "valu" and "cpu_baseline" not in out
     cal = out["exchange_calibration"]
     if exchange == "auto":      # measured before the timed region: peer copies against the all-gather, same on every rank
@@ -171,7 +172,7 @@ def test_bench_nccl_backend_one_rank_force_collective(exchange, overlap):
     why = out["exchange"].pop("fallback_reason")
     assert (why is None) if (exchange != "auto" or kind == "peer_copies") else why.startswith("calibration:")
     assert out["exchange"] == {"kind": kind, "overlapped": overlap, "bytes_per_rank": 12 * 65536 * 4, "verified": True,
-                               "requested": exchange}
+                               "requested": exchange, "peer_copies_disabled": False}
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
     assert out["roofline"]["bound"] == "valu" and out["shards"] == [[0, 65536]]
     assert (out["exchange_calibration"] is not None) == (exchange == "auto")

@@ -1,0 +1,35 @@
+"""GPU box: the host-pointer ABI with per-rollout controls (105 MB of pageable NumPy memory, BASELINE configs[2] shape)
+against the number of staging threads (VDYN_COPY_THREADS, read when a handle makes its first large copy): one child
+process per setting.  usage: python tools/host_abi_threads.py [threads ...]"""
+import json
+import os
+import subprocess
+import sys
+
+CHILD = r"""
+import importlib, sys, time, json, os
+import numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("python-motionplanning_amd")
+W = pkg.workloads
+s0, tab, pid = W.config3(65536, 200, np.float32)
+ctrl = W.expand_shared_controls(tab, pid)
+vm = pkg.VehicleModel(2.906, np.deg2rad(30), 1e-3, device=0)
+for _ in range(3):
+    vm.rollout(s0, ctrl)
+ts = []
+for _ in range(9):
+    t0 = time.perf_counter(); vm.rollout(s0, ctrl); ts.append(time.perf_counter() - t0)
+tt = []
+for _ in range(9):
+    t0 = time.perf_counter(); vm.rollout(s0, tab, path_id=pid); tt.append(time.perf_counter() - t0)
+print(json.dumps({"threads": os.environ.get("VDYN_COPY_THREADS"), "per_rollout_ms_median": float(np.median(ts)) * 1e3,
+                  "per_rollout_ms_min": min(ts) * 1e3, "shared_ms_median": float(np.median(tt)) * 1e3, "MB": ctrl.nbytes / 1e6}))
+"""
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for th in (sys.argv[1:] or ["1", "2", "4", "8", "12", "16"]):
+        env = dict(os.environ, VDYN_COPY_THREADS=th)
+        r = subprocess.run([sys.executable, "-c", CHILD % root], env=env, capture_output=True, text=True, timeout=300)
+        print(r.stdout.strip() or r.stderr[-500:], flush=True)
