@@ -15,8 +15,42 @@
 #include <vector>
 
 #include <sched.h>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 
 #include "vdyn_internal.hpp"
+
+// One slice of a staging copy.  The destination is written once and next read by a DMA engine (or, on the way out, by
+// the caller much later): non-temporal stores keep it out of the caches and spare the read-for-ownership of every
+// destination line, which an ordinary memcpy of a 512 KB slice pays (glibc switches to streaming stores only for much
+// larger copies).  VDYN_COPY_NT=0 selects plain memcpy (A/B on the GPU box: tools/host_abi_threads.py).
+static void stream_copy(char *dst, const char *src, size_t n)
+{
+#if defined(__x86_64__)
+    static const bool nt = [] { const char *e = std::getenv("VDYN_COPY_NT"); return !(e && e[0] == '0'); }();
+    if (nt && n >= 4096) {
+        const size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+        if (head) { std::memcpy(dst, src, head); dst += head; src += head; n -= head; }
+        const size_t blocks = n / 64;
+        for (size_t i = 0; i < blocks; ++i) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src)),
+                          b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 16)),
+                          c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32)),
+                          d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst), a);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 16), b);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 32), c);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 48), d);
+            src += 64;
+            dst += 64;
+        }
+        _mm_sfence();
+        n -= blocks * 64;
+    }
+#endif
+    if (n) std::memcpy(dst, src, n);
+}
 
 // Host copies of the _host entry points (caller's pageable memory <-> the handle's pinned staging buffer).  One thread
 // moves 8-12 GB/s; the PCIe link behind it moves several times that, so a large staging copy -- 105 MB of per-rollout
@@ -101,7 +135,7 @@ private:
             const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
             if (i >= slices_) break;
             const size_t off = i * kSliceBytes;
-            std::memcpy(dst_ + off, src_ + off, std::min(kSliceBytes, bytes_ - off));
+            stream_copy(dst_ + off, src_ + off, std::min(kSliceBytes, bytes_ - off));
             ++mine;
         }
         if (mine) {

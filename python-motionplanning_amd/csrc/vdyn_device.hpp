@@ -630,14 +630,24 @@ __device__ __forceinline__ bool rk4_step(const DevParams<T> &P, const T s[10], T
 }
 
 // One step for one lane: the FAST path, then SAFE for the lanes that need it.
-// The test is wave-uniform (one scalar branch, normally not taken).  Behind it EVERY lane of the wave runs the SAFE
-// step under the full exec mask and each value is then SELECTED per lane (a lane that stayed in range keeps its FAST
-// result bit for bit).  Until round 5 the redo sat in a divergent region, `if (!ok) { SAFE }`, which costs a wave
-// exactly as much -- and whose join block is where this compiler (ROCm 7.2's LLVM) can place register-allocator
+// The test is wave-uniform (one scalar branch, normally not taken).
+//
+// fp64 lane kernels without diagnostics (kSelectRedo): behind that branch EVERY lane of the wave runs the SAFE step under
+// the full exec mask and each value is then SELECTED per lane -- a lane that stayed in range keeps its FAST result bit
+// for bit, the wave pays what a masked redo pays.  Until round 5 the redo was a divergent region everywhere,
+// `if (!ok) { SAFE }`, and its join block is where this compiler (ROCm 7.2's clang-22) can place register-allocator
 // copies of loop-carried values IN FRONT of the exec restore, i.e. under the redo's partial mask: lanes that did not
-// take the redo then keep the previous step's value (x, y parked in AGPRs: round 4's "RowReader" miscompare, and the
-// shipped fp64 k = 12 shared-table general-chain instance; tools/isa/exec_restore_audit.py).
-// A uniform branch has no exec mask to restore, so its join cannot be hit.
+// take the redo then keep the previous step's value.  That is what round 4's "RowReader" miscompare was (x, y parked in
+// AGPRs, fp64 k = 12), and the shipped fp64 k = 12 shared-table general-chain instance had it too
+// (tools/isa/exec_restore_audit.py, tests/test_isa_audit.py).  It takes the register pressure of
+// exactly this family -- 512 registers, hundreds of spilled scalars -- so this family no longer HAS the join: a uniform
+// branch restores no exec mask.
+// Everything else keeps the divergent form, held to "no vector instruction in front of an exec restore at a join" by the
+// audit over the built library: the fp32 kernels (measured on one box against round 4's library: the select form cost
+// the per-rollout-controls kernel 4.3 % and every fp32 lane kernel 12 VGPRs -- both results of a redone step are alive
+// at the select -- for no instance the audit had flagged), the diagnostic instances (the same, times 40 values: 230-340 B
+// of scratch instead of 12-20 and +8.7 % on the single-vehicle frame), and the wheel-parallel kernels (the select form
+// crashes the compiler there: vdyn_quad.hpp).
 __device__ __forceinline__ float atan_lib(float x) { return ::atanf(x); }
 __device__ __forceinline__ double atan_lib(double x) { return ::atan(x); }
 
@@ -649,34 +659,29 @@ __device__ __forceinline__ void rk4_advance(const DevParams<T> &P, T s[10], T &a
     T sn[10], axn, ayn;
     const bool ok = rk4_step<T, K2, DIAG, false, CS, PRE, FITSRC>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot,
                                                                 outputs, sd0, cd0);
-    if (Math<T, false>::kHasRangeLimit) {
-#ifdef VDYN_MASKED_REDO             // diagnostic build only (tools/isa/reader_all.hip): the divergent form, for the reproducer
-        if (__builtin_expect(__any(!ok) != 0, 0)) {
-            if (!ok) rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, state_dot, outputs);
-        }
+#ifdef VDYN_MASKED_REDO             // diagnostic build only (tools/isa/reader_all.hip): the divergent form everywhere
+    constexpr bool kSelectRedo = false;
 #else
+    constexpr bool kSelectRedo = !DIAG && sizeof(T) == 8;
+#endif
+    if (Math<T, false>::kHasRangeLimit) {
         if (__builtin_expect(__any(!ok) != 0, 0)) {
-            T sr[10], axr, ayr, sdr[10];
-            Outputs18<T> outr;
             T dl[4] = {delta[0], delta[1], delta[2], delta[3]};
             if (PRE == 2) {         // delta[0] is the tangent of the (front) steering angle
                 dl[0] = dl[1] = atan_lib(delta[0]);
                 dl[2] = dl[3] = T(0);
             }
-            rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, dl, tq, mu, h, sr, axr, ayr, DIAG ? sdr : nullptr,
-                                            DIAG ? &outr : nullptr);
+            if constexpr (kSelectRedo) {
+                T sr[10], axr, ayr;
+                rk4_step<T, K2, false, true, CS>(P, s, ax, ay, dl, tq, mu, h, sr, axr, ayr, nullptr, nullptr);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) sn[i] = ok ? sn[i] : sr[i];
-            axn = ok ? axn : axr;
-            ayn = ok ? ayn : ayr;
-            if (DIAG) {
-#pragma unroll
-                for (int i = 0; i < 10; ++i) state_dot[i] = ok ? state_dot[i] : sdr[i];
-#pragma unroll
-                for (int i = 0; i < 18; ++i) outputs->v[i] = ok ? outputs->v[i] : outr.v[i];
+                for (int i = 0; i < 10; ++i) sn[i] = ok ? sn[i] : sr[i];
+                axn = ok ? axn : axr;
+                ayn = ok ? ayn : ayr;
+            } else {
+                if (!ok) rk4_step<T, K2, DIAG, true, CS>(P, s, ax, ay, dl, tq, mu, h, sn, axn, ayn, state_dot, outputs);
             }
         }
-#endif
     }
 #pragma unroll
     for (int i = 0; i < 10; ++i) s[i] = sn[i];

@@ -654,21 +654,17 @@ struct StepEngine<float> {
             xy = fma2(h6, A.xy, S.xy);
         }
         if (__builtin_expect(__any(!ok) != 0, 0)) {
-            // every lane runs the redo under the full exec mask; a lane that stayed in range keeps its FAST values
-            // (rk4_advance, vdyn_device.hpp: why this is not a divergent region)
-            float s[10], sn[10], axn, ayn;
+            if (!ok) {
+                float s[10], sn[10], axn, ayn;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) s[i] = X.get(i);
-            float dl[4] = {delta[0], delta[1], delta[2], delta[3]};
-            if (PRE == 2) dl[0] = dl[1] = ::atanf(delta[0]);        // delta[0] is tan(delta)
-            rk4_step<float, K2, false, true, CS>(P, s, X.axy.x, X.axy.y, dl, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
-            uv = ok ? uv : f2{sn[0], sn[1]}; wy = ok ? wy : f2{sn[2], sn[7]}; wf = ok ? wf : f2{sn[3], sn[4]};
-            wr = ok ? wr : f2{sn[5], sn[6]}; xy = ok ? xy : f2{sn[8], sn[9]};
-            axy_n = ok ? axy_n : f2{axn, ayn};
-            if (COMP) {                                              // the redone step starts a fresh sum
-                const f2 z = splat(0.0f);
-                X.cuv = ok ? X.cuv : z; X.cwy = ok ? X.cwy : z; X.cwf = ok ? X.cwf : z; X.cwr = ok ? X.cwr : z;
-                X.cxy = ok ? X.cxy : z;
+                for (int i = 0; i < 10; ++i) s[i] = X.get(i);
+                float dl[4] = {delta[0], delta[1], delta[2], delta[3]};
+                if (PRE == 2) dl[0] = dl[1] = ::atanf(delta[0]);        // delta[0] is tan(delta)
+                rk4_step<float, K2, false, true, CS>(P, s, X.axy.x, X.axy.y, dl, tq, mu, h, sn, axn, ayn, nullptr, nullptr);
+                uv = f2{sn[0], sn[1]}; wy = f2{sn[2], sn[7]}; wf = f2{sn[3], sn[4]}; wr = f2{sn[5], sn[6]};
+                xy = f2{sn[8], sn[9]};
+                axy_n = f2{axn, ayn};
+                if (COMP) X.cuv = X.cwy = X.cwf = X.cwr = X.cxy = splat(0.0f);   // the redone step starts a fresh sum
             }
         }
         X.uv = uv; X.wy = wy; X.wf = wf; X.wr = wr; X.xy = xy;
@@ -719,16 +715,8 @@ struct StepEngine<float> {
         o.v[8] = FzF.x; o.v[9] = FzF.y; o.v[10] = FzR.x; o.v[11] = FzR.y;
         o.v[12] = g.s[0].x; o.v[13] = g.s[0].y; o.v[14] = g.s[1].x; o.v[15] = g.s[1].y;
         o.v[16] = g.fxt.x; o.v[17] = g.fyt.x;
-        if (__builtin_expect(__any(!ok) != 0, 0)) {      // full-exec redo + per-lane select (rk4_advance, vdyn_device.hpp)
-            float sr[10], axr, ayr, sdr[10];
-            Outputs18<float> outr;
-            rk4_step<float, K2, true, true, CS>(P, s, ax, ay, delta, tq, mu, h, sr, axr, ayr, sdr, &outr);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) { sn[i] = ok ? sn[i] : sr[i]; sd[i] = ok ? sd[i] : sdr[i]; }
-#pragma unroll
-            for (int i = 0; i < 18; ++i) o.v[i] = ok ? o.v[i] : outr.v[i];
-            axn = ok ? axn : axr;
-            ayn = ok ? ayn : ayr;
+        if (__builtin_expect(__any(!ok) != 0, 0)) {
+            if (!ok) rk4_step<float, K2, true, true, CS>(P, s, ax, ay, delta, tq, mu, h, sn, axn, ayn, sd, &o);
         }
 #pragma unroll
         for (int i = 0; i < 10; ++i) s[i] = sn[i];

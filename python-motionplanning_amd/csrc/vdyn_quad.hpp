@@ -176,8 +176,8 @@ __device__ __forceinline__ bool rk4_step_quad(const DevParams<T> &P, const Wheel
 }
 
 // FAST step, then SAFE for whole quads in which any lane left the validated range.
-// (The lane kernels run their redo under the full exec mask with a select per value: rk4_advance, vdyn_device.hpp.  The
-// same form HERE crashes this compiler -- ROCm 7.2's clang-22 segfaults in the greedy register allocator,
+// (The fp64 lane kernels run their redo under the full exec mask with a select per value: rk4_advance, vdyn_device.hpp.
+// The same form HERE crashes this compiler -- ROCm 7.2's clang-22 segfaults in the greedy register allocator,
 // VirtRegAuxInfo::isRematerializable, on rollout_quad_kernel<double, 2, 0, false, true> -- so the wheel-parallel
 // kernels keep the divergent region; tests/test_isa_audit.py holds every shipped instance, these included, to "no
 // vector instruction in front of an exec restore at a join".)

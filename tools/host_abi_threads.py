@@ -23,13 +23,14 @@ for _ in range(9):
 tt = []
 for _ in range(9):
     t0 = time.perf_counter(); vm.rollout(s0, tab, path_id=pid); tt.append(time.perf_counter() - t0)
-print(json.dumps({"threads": os.environ.get("VDYN_COPY_THREADS"), "per_rollout_ms_median": float(np.median(ts)) * 1e3,
+print(json.dumps({"threads": os.environ.get("VDYN_COPY_THREADS"), "nt_stores": os.environ.get("VDYN_COPY_NT", "1"), "per_rollout_ms_median": float(np.median(ts)) * 1e3,
                   "per_rollout_ms_min": min(ts) * 1e3, "shared_ms_median": float(np.median(tt)) * 1e3, "MB": ctrl.nbytes / 1e6}))
 """
 
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for th in (sys.argv[1:] or ["1", "2", "4", "8", "12", "16"]):
-        env = dict(os.environ, VDYN_COPY_THREADS=th)
-        r = subprocess.run([sys.executable, "-c", CHILD % root], env=env, capture_output=True, text=True, timeout=300)
-        print(r.stdout.strip() or r.stderr[-500:], flush=True)
+        for nt in ("1", "0"):           # streaming stores into the staging buffer, or plain memcpy
+            env = dict(os.environ, VDYN_COPY_THREADS=th, VDYN_COPY_NT=nt)
+            r = subprocess.run([sys.executable, "-c", CHILD % root], env=env, capture_output=True, text=True, timeout=300)
+            print(r.stdout.strip() or r.stderr[-500:], flush=True)
