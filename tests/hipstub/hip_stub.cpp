@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "../../python-motionplanning_amd/csrc/vdyn_internal.hpp"
@@ -383,6 +384,99 @@ long long hipstub_live_streams_and_events(void)
 
 }  // extern "C"
 
+// ------------------------------------------------------------------- level 2: the REAL launchers' host halves ----
+// -DHIPSTUB_REAL_LAUNCHERS (tests/hipstub/build_launchers.sh): this file, csrc/vdyn_capi.hip and BOTH kernel translation
+// units are compiled by hipcc --cuda-host-only (the real HIP headers, no device code) under the sanitizers, so the
+// launchers' host code runs too -- make_dev_params, the long-double tire fits and their cache, the fleet / candidate
+// table builders, chunk and LDS sizing, the choice of kernel instance.  A launch then arrives here as hipLaunchKernel:
+// its geometry is checked (block 1..1024 threads, grid >= 1, dynamic LDS within the function's limit and the CU's
+// 160 KB) and it is counted per kernel name; nothing is computed, so the driver skips its content checks.
+#ifdef HIPSTUB_REAL_LAUNCHERS
+namespace {
+// (filled by the translation units' module constructors, which may run before this file's statics are constructed)
+std::map<const void *, std::string> &kernel_names()
+{
+    static auto *m = new std::map<const void *, std::string>;
+    return *m;
+}
+#define g_kernel_names kernel_names()
+std::map<const void *, int> g_max_dyn_lds;
+std::map<std::string, long long> g_launches;
+struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
+std::vector<CallCfg> g_cfg;
+}  // namespace
+extern "C" {
+void **__hipRegisterFatBinary(const void *)
+{
+    static void *handle = nullptr;
+    return &handle;
+}
+void __hipRegisterFunction(void **, const void *host_fn, char *, const char *device_name, unsigned, void *, void *, void *,
+                           void *, int *)
+{
+    g_kernel_names[host_fn] = device_name;
+}
+void __hipRegisterVar(void **, void *, char *, const char *, int, size_t, int, int) {}
+void __hipUnregisterFatBinary(void **) {}
+hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shmem, hipStream_t stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_cfg.push_back({grid, block, shmem, stream});
+    return hipSuccess;
+}
+hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hipStream_t *stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (g_cfg.empty()) die("__hipPopCallConfiguration without a push");
+    *grid = g_cfg.back().grid;
+    *block = g_cfg.back().block;
+    *shmem = g_cfg.back().shmem;
+    *stream = g_cfg.back().stream;
+    g_cfg.pop_back();
+    return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void *fn, hipFuncAttribute attr, int value)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!g_kernel_names.count(fn)) die("hipFuncSetAttribute on a function that was never registered");
+    if (attr == hipFuncAttributeMaxDynamicSharedMemorySize) {
+        if (value < 0 || value > 160 * 1024) die("hipFuncSetAttribute: dynamic LDS beyond the CU's 160 KB");
+        g_max_dyn_lds[fn] = value;
+    }
+    return hipSuccess;
+}
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t shmem, hipStream_t stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    init();
+    auto it = g_kernel_names.find(fn);
+    if (it == g_kernel_names.end()) die("hipLaunchKernel: a function that was never registered");
+    const unsigned long long threads = (unsigned long long)block.x * block.y * block.z;
+    if (threads == 0 || threads > 1024) { std::fprintf(stderr, "hipstub: %s: block of %llu threads\n", it->second.c_str(), threads); std::abort(); }
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0 || grid.x > 0x7fffffffu) { std::fprintf(stderr, "hipstub: %s: grid %u x %u x %u\n", it->second.c_str(), grid.x, grid.y, grid.z); std::abort(); }
+    const size_t limit = g_max_dyn_lds.count(fn) ? (size_t)g_max_dyn_lds[fn] : (size_t)64 * 1024;
+    if (shmem > limit) { std::fprintf(stderr, "hipstub: %s: %zu B of dynamic LDS, limit %zu\n", it->second.c_str(), shmem, limit); std::abort(); }
+    if (!args) die("hipLaunchKernel: null argument array");
+    if (!g_streams.count(sp(stream))) die("hipLaunchKernel: unknown stream");
+    ++g_launches[it->second];
+    enqueue(stream, [] {});
+    return hipSuccess;
+}
+long long hipstub_launch_count(const char *substring)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    long long n = 0;
+    for (auto &kv : g_launches)
+        if (!substring || kv.first.find(substring) != std::string::npos) n += kv.second;
+    return n;
+}
+long long hipstub_distinct_kernels(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return (long long)g_launches.size();
+}
+}  // extern "C"
+#else
 // --------------------------------------------------------------------------------------------- the launchers -----
 // Stand-ins for csrc/vdyn_kernels.hip's launch_* (the interface vdyn_capi.hip calls).  The rollout family is an exact
 // toy integrator with the REAL kernels' composition property -- rollout(a) then rollout(b) == rollout(a + b), trajectory
@@ -671,3 +765,4 @@ HIPSTUB_INSTANTIATE(float)
 HIPSTUB_INSTANTIATE(double)
 
 }  // namespace vdyn
+#endif  // HIPSTUB_REAL_LAUNCHERS

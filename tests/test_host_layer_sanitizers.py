@@ -58,3 +58,29 @@ def test_the_stub_exports_what_the_header_declares(asan_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
     have = set(re.findall(r" T (vdyn_\w+)", out))
     assert set(sigs) <= have, sorted(set(sigs) - have)
+
+
+def test_real_launchers_host_halves_under_asan_ubsan():
+    """Level 2: csrc/vdyn_capi.hip AND both kernel translation units, compiled by hipcc --cuda-host-only (the real HIP
+    headers, host code only) under the sanitizers, linked with the stub runtime (tests/hipstub/build_launchers.sh).  The
+    launchers' host halves run for real -- make_dev_params, the long-double tire fits and their cache, the per-wheel /
+    per-axle fit tables, fleet and candidate tables, LDS chunking, the choice of kernel instance -- for the default tires,
+    one C per axle, four different C, a shape factor no fit covers, a negative stiffness, and a fleet mixing them.  A
+    launch ends in the stub's hipLaunchKernel: block of 1..1024 threads, grid >= 1, dynamic LDS within the limit the
+    launcher asked for (hipFuncSetAttribute) and the CU's 160 KB; every kernel family must have been launched."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    rt = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+    if not os.path.exists(hipcc) or not os.path.exists(rt):
+        pytest.skip("needs ROCm's hipcc and clang's shared ASan runtime")
+    r = subprocess.run([os.path.join(STUB, "build_launchers.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, LD_PRELOAD=rt, HIPSTUB_LEVEL="2", HIPSTUB_SEED="1",
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_host_layer_driver.py"),
+                        os.path.join(STUB, "_build", "libvdyn_host_asan.so")], capture_output=True, text=True, env=env,
+                       cwd=REPO, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "AddressSanitizer" not in tail and "runtime error" not in tail and "hipstub:" not in tail, tail
+    assert "level 2:" in r.stdout and "distinct kernel instances" in r.stdout and "checks passed" in r.stdout
