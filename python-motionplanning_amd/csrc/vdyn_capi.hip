@@ -868,11 +868,18 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
 {
     const size_t e = sizeof(T) * (size_t)a.n, rows = (size_t)h->state_rows;
     const size_t step_bytes = (size_t)a.k * e, ctrl_bytes = (size_t)a.H * step_bytes;
-    // chunk: about an eighth of the horizon's bytes, 4 .. 32 MB, whole steps, a multiple of traj_stride
-    const size_t want = std::min<size_t>(std::max<size_t>(ctrl_bytes / 8, 4u << 20), 32u << 20);
+    // chunk: about a twelfth of the horizon's bytes, 2 .. 16 MB, whole steps, a multiple of traj_stride.  The first two
+    // chunks are a quarter and a half of that: nothing overlaps the first chunk's host copy and upload (the pipeline's
+    // fill), so it is kept short; measured on one box, 105 MB: 2.47 ms with eight equal chunks of 13 MB
+    const size_t want = std::min<size_t>(std::max<size_t>(ctrl_bytes / 12, 2u << 20), 16u << 20);
     int64_t hc = std::max<int64_t>(1, (int64_t)(want / step_bytes));
-    if (a.traj) hc = std::max<int64_t>(a.traj_stride, hc / a.traj_stride * a.traj_stride);
+    const int64_t unit = a.traj ? a.traj_stride : 1;
+    hc = std::max<int64_t>(unit, hc / unit * unit);
     hc = std::min<int64_t>(hc, a.H);
+    auto ramp = [&](int c) {                                    // steps of chunk c
+        const int64_t part = c == 0 ? hc / 4 : c == 1 ? hc / 2 : hc;
+        return std::max<int64_t>(unit, part / unit * unit);
+    };
     const size_t chunk_bytes = (size_t)hc * step_bytes;
     const size_t traj_bytes = a.traj ? (size_t)(a.H / a.traj_stride) * 12 * e : 0;
     auto r256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -908,9 +915,9 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
     const char *src = reinterpret_cast<const char *>(a.ctrl);
     int64_t t0 = 0, traj_row = 0;
     int c = 0;
-    for (; t0 < a.H; t0 += hc, ++c) {
+    for (int64_t hn = 0; t0 < a.H; t0 += hn, ++c) {
         const int b = c & 1;
-        const int64_t hn = std::min<int64_t>(hc, a.H - t0);
+        hn = std::min<int64_t>(ramp(c), a.H - t0);
         const size_t bytes = (size_t)hn * step_bytes;
         // pinned ctrl[b] was the source of chunk c - 2's upload: that copy must have run before the host overwrites it
         if (c >= 2) VDYN_PIPE(hipEventSynchronize(h->ev_h2d[b]));
