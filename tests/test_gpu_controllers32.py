@@ -157,7 +157,7 @@ def test_fp32_closed_loop_seed_sweep(gpu_vm, oracle, workloads, seed, every, H):
 
 def test_fp32_closed_loop_seed_sweep_pooled(gpu_vm, oracle, workloads):
     """Over the six cases together (49152 vehicles): the kernel's outlier count against the float oracle's, factor 2, no
-    additive slack; the table goes to gpurun_out/ (committed copy: profiles/r04_closed_loop_seed_sweep.txt).  Cases the
+    additive slack; the table goes to gpurun_out/ (committed copy: profiles/r05_closed_loop_seed_sweep.txt).  Cases the
     session has not run (a `-k` selection) are computed here: this test never passes by skipping."""
     import os
     for case in SWEEP_CASES:

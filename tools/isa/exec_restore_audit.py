@@ -208,7 +208,7 @@ def main(argv):
         for fd in allf:
             print(f"{fd['file']}:{fd['line']}: {fd['kernel_demangled']} block {fd['block']}: {len(fd['before'])} vector "
                   f"instruction(s) before `{fd['restore']}`: " + "; ".join(fd["before"][:6]) + (" ..." if len(fd["before"]) > 6 else ""))
-        print(f"{len(allf)} block(s) flagged in {len(files)} file(s)")
+        print(f"{len(allf)} block(s) flagged in " + (files[0] + " of the library" if "--lib" in argv else f"{len(files)} file(s)"))
     return 1 if allf else 0
 
 
