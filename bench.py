@@ -400,8 +400,19 @@ def supervise(args, argv, script):
                     "VDYN_BENCH_ABORT_FILE": os.path.join(cdir, f"a{k}.failed")})
         env.update(env_extra)                # a value of None removes the variable
         cmd = [sys.executable, script, *child_argv]
-        proc = subprocess.Popen(cmd, env={a: b for a, b in env.items() if b is not None},
+
+        def die_with_parent():
+            # (in the child, before exec) should this supervisor be killed -- the agent tearing the job down, the driver's
+            # time limit -- the kernel ends the worker too: no orphan keeps a GPU
+            try:
+                import ctypes
+                ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, 9)        # PR_SET_PDEATHSIG, SIGKILL
+            except Exception:                                               # noqa: BLE001
+                pass
+
+        proc = subprocess.Popen(cmd, env={a: b for a, b in env.items() if b is not None}, preexec_fn=die_with_parent,
                                 stdout=subprocess.PIPE if rank == 0 else None, text=True if rank == 0 else None)
+        current["proc"] = proc
         held = []
 
         def pump():
@@ -433,6 +444,19 @@ def supervise(args, argv, script):
         if rc != 0:
             put(f"a{k}.failed")
         return rc, (held[-1] if held else None)
+
+    # SIGTERM / SIGINT to a supervisor (torch.distributed.run ending the job) go on to its worker before it leaves
+    import signal
+    current = {"proc": None}
+
+    def forward(signum, _frame):
+        pr = current["proc"]
+        if pr is not None and pr.poll() is None:
+            pr.terminate()
+        sys.exit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
 
     def wait_decision(k, limit_s):
         t_end = time.monotonic() + limit_s

@@ -189,3 +189,43 @@ def test_self_launch_happens_before_torch_is_imported():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
     assert res.returncode == 7, res.stderr[-2000:]      # the child's exit code is ours
+
+
+def test_ending_the_launcher_ends_the_workers_too(tmp_path):
+    """The ranks' real work runs in children of the supervisors.  When the job is torn down from above (the agent's
+    SIGTERM, or a plain kill of a supervisor: PR_SET_PDEATHSIG), no worker may be left behind holding a GPU."""
+    import signal
+    import time
+    import psutil
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-extra", "--horizon", "12",
+            "--rollouts-per-gpu", "70", "--no-cpu-baseline", "--run-timeout-s", "300"]
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.spawn_ranks(2, %r, script=%r))" % (REPO, argv, ENTRY))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FAKE_P2P, VDYN_TEST_P2P_FAULT="hang_in_start")           # the workers sit in their first push for good
+    top = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        me = psutil.Process(top.pid)
+        deadline = time.time() + 120
+        workers = []
+        while time.time() < deadline:
+            procs = me.children(recursive=True)
+            workers = [p for p in procs if "VDYN_BENCH_WORKER" in (p.environ() if p.is_running() else {})]
+            if len(workers) == 2:
+                break
+            time.sleep(0.5)
+        assert len(workers) == 2, "two worker ranks expected under two supervisors"
+        supervisors = [w.parent() for w in workers]
+        time.sleep(3.0)                                                 # let them reach the hang
+        supervisors[1].send_signal(signal.SIGKILL)                      # a supervisor dies without a word ...
+        top.send_signal(signal.SIGTERM)                                 # ... and the launcher is asked to stop
+        gone, alive = psutil.wait_procs(workers + supervisors, timeout=60)
+        assert not alive, f"left behind: {[(p.pid, p.cmdline()[-3:]) for p in alive]}"
+    finally:
+        try:
+            for p in psutil.Process(top.pid).children(recursive=True):
+                p.kill()
+        except psutil.NoSuchProcess:
+            pass
+        top.kill()
+        top.wait(timeout=30)
