@@ -205,8 +205,8 @@ struct VdynHandle {
     // _host entry points: worker threads of the staging copies (created with the first large copy), the upload stream
     // of the pipelined rollout and its events (rollout_host_pipelined)
     CopyPool *pool = nullptr;
-    hipStream_t stage_stream = nullptr;
-    hipEvent_t ev_h2d[2] = {}, ev_kernel[2] = {};
+    hipStream_t stage_stream = nullptr, down_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {}, ev_kernel[2] = {}, ev_d2h[2] = {};
 
     void host_copy(void *dst, const void *src, size_t bytes)
     {
@@ -365,9 +365,11 @@ void vdyn_destroy(VdynHandle *h)
     }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     if (h->stage_stream) { (void)hipStreamSynchronize(h->stage_stream); (void)hipStreamDestroy(h->stage_stream); }
+    if (h->down_stream) { (void)hipStreamSynchronize(h->down_stream); (void)hipStreamDestroy(h->down_stream); }
     for (int i = 0; i < 2; ++i) {
         if (h->ev_h2d[i]) (void)hipEventDestroy(h->ev_h2d[i]);
         if (h->ev_kernel[i]) (void)hipEventDestroy(h->ev_kernel[i]);
+        if (h->ev_d2h[i]) (void)hipEventDestroy(h->ev_d2h[i]);
     }
     delete h->pool;
     delete h;
@@ -863,16 +865,97 @@ int planar_model_host(VdynHandle *h, int64_t n, const T *state, const T *ctrl12,
 //   pinned: [state0 | terminal | ctrl 0 | ctrl 1 | traj]      device: [state A | state B | ctrl 0 | ctrl 1 | traj]
 static constexpr size_t kPipelineMinBytes = 8u << 20;      // below this the whole-buffer staging is as fast
 
+static int ensure_pipeline(VdynHandle *h)
+{
+    VDYN_HIP(h, hipSetDevice(h->device));
+    if (!h->stage_stream) VDYN_HIP(h, hipStreamCreateWithFlags(&h->stage_stream, hipStreamNonBlocking));
+    if (!h->down_stream) VDYN_HIP(h, hipStreamCreateWithFlags(&h->down_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->ev_h2d[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
+        if (!h->ev_kernel[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_kernel[i], hipEventDisableTiming));
+        if (!h->ev_d2h[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_d2h[i], hipEventDisableTiming));
+    }
+    return VDYN_OK;
+}
+
+// byte offsets of the regions of a staging buffer (the same layout in pinned and in device memory), 256-byte aligned
+struct Layout {
+    size_t total = 0;
+    size_t add(size_t bytes)
+    {
+        const size_t off = total;
+        total += (bytes + 255) & ~(size_t)255;
+        return off;
+    }
+};
+
+// The way OUT of a chunked run: rows a kernel chunk wrote into device buffer b cross PCIe on the download stream into
+// pinned buffer b while the next chunk is integrated, and the worker threads copy pinned buffer b ^ 1 -- the chunk before
+// -- into the caller's memory meanwhile.  Two buffers each: chunk c + 2's kernel waits (on the device) for chunk c's
+// download, and the download of chunk c + 2 is queued only after the host has emptied pinned buffer b (program order).
+// Staging memory is two chunks, not the whole log: 65536 vehicles x 100 sub-steps of DataLog are 1.2 GB.
+struct Downloader {
+    struct Seg { size_t off, dev_bytes; void *dst; };   // region of the chunk buffer -> the caller's memory
+    VdynHandle *h;
+    char *dev[2], *pin[2];
+    std::vector<Seg> pending[2];
+    bool busy[2] = {false, false};
+    Downloader(VdynHandle *h_, char *dev0, char *dev1, char *pin0, char *pin1) : h(h_), dev{dev0, dev1}, pin{pin0, pin1} {}
+
+    // before chunk c's kernel is launched: its device buffer must have been downloaded (chunk c - 2).  (Today the host
+    // has already waited for that download -- flush() of chunk c - 2 ran during chunk c - 1 -- so this wait never
+    // blocks; it is here so that the buffer discipline does not hang on how the host happens to be ordered.)
+    int before_kernel(int c)
+    {
+        if (c >= 2) VDYN_HIP(h, hipStreamWaitEvent(h->stream, h->ev_d2h[c & 1], 0));
+        return VDYN_OK;
+    }
+    // after chunk c's kernel (its ev_kernel[b] recorded): queue the download of `segs`, then empty the other buffer
+    int after_kernel(int c, const std::vector<Seg> &segs)
+    {
+        const int b = c & 1;
+        VDYN_HIP(h, hipStreamWaitEvent(h->down_stream, h->ev_kernel[b], 0));
+        for (const Seg &sg : segs)
+            if (sg.dev_bytes) VDYN_HIP(h, hipMemcpyAsync(pin[b] + sg.off, dev[b] + sg.off, sg.dev_bytes, hipMemcpyDeviceToHost, h->down_stream));
+        VDYN_HIP(h, hipEventRecord(h->ev_d2h[b], h->down_stream));
+        pending[b] = segs;
+        busy[b] = true;
+        return flush(b ^ 1);
+    }
+    int flush(int b)
+    {
+        if (!busy[b]) return VDYN_OK;
+        VDYN_HIP(h, hipEventSynchronize(h->ev_d2h[b]));
+        for (const Seg &sg : pending[b]) h->host_copy(sg.dst, pin[b] + sg.off, sg.dev_bytes);
+        busy[b] = false;
+        return VDYN_OK;
+    }
+    int finish(int chunks) { if (int rc = flush(chunks & 1)) return rc; return flush((chunks & 1) ^ 1); }
+};
+
+// (inside the pipelined functions: a failed HIP call drains the streams, then reports)
+#define VDYN_PIPE(expr)                                                     \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) return drain(h->fail_hip(#expr, e_));         \
+    } while (0)
+
+template <typename T>
+int closed_loop_dev(VdynHandle *h, const VdynCtrlGains *g, const vdyn::ClosedLoopArgs<T> &a, bool update_only,
+                    void *stream);
+
 template <typename T>
 int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
 {
     const size_t e = sizeof(T) * (size_t)a.n, rows = (size_t)h->state_rows;
-    const size_t step_bytes = (size_t)a.k * e, ctrl_bytes = (size_t)a.H * step_bytes;
+    const size_t step_bytes = (size_t)a.k * e;
+    // what a step moves: its controls up and, with a trajectory, 12 rows down every traj_stride steps
+    const size_t step_moves = step_bytes + (a.traj ? 12 * e / (size_t)a.traj_stride : 0);
     // chunk: about a twelfth of the horizon's bytes, 2 .. 16 MB, whole steps, a multiple of traj_stride.  The first two
     // chunks are a quarter and a half of that: nothing overlaps the first chunk's host copy and upload (the pipeline's
-    // fill), so it is kept short; measured on one box, 105 MB: 2.47 ms with eight equal chunks of 13 MB
-    const size_t want = std::min<size_t>(std::max<size_t>(ctrl_bytes / 12, 2u << 20), 16u << 20);
-    int64_t hc = std::max<int64_t>(1, (int64_t)(want / step_bytes));
+    // fill), so it is kept short; measured on one box, 105 MB: 2.47 ms with eight equal chunks of 13 MB, 2.42 ramped
+    const size_t want = std::min<size_t>(std::max<size_t>((size_t)a.H * step_moves / 12, 2u << 20), 16u << 20);
+    int64_t hc = std::max<int64_t>(1, (int64_t)(want / step_moves));
     const int64_t unit = a.traj ? a.traj_stride : 1;
     hc = std::max<int64_t>(unit, hc / unit * unit);
     hc = std::min<int64_t>(hc, a.H);
@@ -881,37 +964,28 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
         return std::max<int64_t>(unit, part / unit * unit);
     };
     const size_t chunk_bytes = (size_t)hc * step_bytes;
-    const size_t traj_bytes = a.traj ? (size_t)(a.H / a.traj_stride) * 12 * e : 0;
-    auto r256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t st = r256(rows * e), cb = r256(chunk_bytes);
-    if (int rc = ensure_scratch(h, 2 * st + 2 * cb + r256(traj_bytes), 2 * st + 2 * cb + r256(traj_bytes))) return rc;
-    VDYN_HIP(h, hipSetDevice(h->device));
-    if (!h->stage_stream) VDYN_HIP(h, hipStreamCreateWithFlags(&h->stage_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-        if (!h->ev_h2d[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
-        if (!h->ev_kernel[i]) VDYN_HIP(h, hipEventCreateWithFlags(&h->ev_kernel[i], hipEventDisableTiming));
-    }
+    const size_t traj_chunk = a.traj ? (size_t)(hc / a.traj_stride) * 12 * e : 0;
+    Layout L;
+    const size_t o_state[2] = {L.add(rows * e), L.add(rows * e)};       // pinned: state0 | terminal; device: state A | state B
+    const size_t o_ctrl[2] = {L.add(chunk_bytes), L.add(chunk_bytes)};
+    const size_t o_traj[2] = {L.add(traj_chunk), L.add(traj_chunk)};
+    if (int rc = ensure_scratch(h, L.total, L.total)) return rc;
+    if (int rc = ensure_pipeline(h)) return rc;
     char *pin = static_cast<char *>(h->h_pinned), *dev = static_cast<char *>(h->d_scratch);
-    char *pin_state = pin, *pin_term = pin + st, *pin_ctrl[2] = {pin + 2 * st, pin + 2 * st + cb}, *pin_traj = pin + 2 * st + 2 * cb;
-    T *dev_state[2] = {reinterpret_cast<T *>(dev), reinterpret_cast<T *>(dev + st)};
-    char *dev_ctrl[2] = {dev + 2 * st, dev + 2 * st + cb};
-    T *dev_traj = a.traj ? reinterpret_cast<T *>(dev + 2 * st + 2 * cb) : nullptr;
+    T *dev_state[2] = {reinterpret_cast<T *>(dev + o_state[0]), reinterpret_cast<T *>(dev + o_state[1])};
+    Downloader down(h, dev + o_traj[0], dev + o_traj[1], pin + o_traj[0], pin + o_traj[1]);
 
-    // On any failure past this point copies may be in flight from / into the staging buffers: drain both streams
+    // On any failure past this point copies may be in flight from / into the staging buffers: drain the streams
     // before the error goes back (the buffers belong to the handle and the next call reuses them).
     auto drain = [&](int rc) {
         (void)hipStreamSynchronize(h->stage_stream);
         (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->down_stream);
         return rc;
     };
-#define VDYN_PIPE(expr)                                                     \
-    do {                                                                    \
-        hipError_t e_ = (expr);                                             \
-        if (e_ != hipSuccess) return drain(h->fail_hip(#expr, e_));         \
-    } while (0)
 
-    h->host_copy(pin_state, a.state0, rows * e);
-    VDYN_PIPE(hipMemcpyAsync(dev_state[0], pin_state, rows * e, hipMemcpyHostToDevice, h->stage_stream));
+    h->host_copy(pin + o_state[0], a.state0, rows * e);
+    VDYN_PIPE(hipMemcpyAsync(dev_state[0], pin + o_state[0], rows * e, hipMemcpyHostToDevice, h->stage_stream));
     const char *src = reinterpret_cast<const char *>(a.ctrl);
     int64_t t0 = 0, traj_row = 0;
     int c = 0;
@@ -921,29 +995,110 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
         const size_t bytes = (size_t)hn * step_bytes;
         // pinned ctrl[b] was the source of chunk c - 2's upload: that copy must have run before the host overwrites it
         if (c >= 2) VDYN_PIPE(hipEventSynchronize(h->ev_h2d[b]));
-        h->host_copy(pin_ctrl[b], src + (size_t)t0 * step_bytes, bytes);
+        h->host_copy(pin + o_ctrl[b], src + (size_t)t0 * step_bytes, bytes);
         // device ctrl[b] is what chunk c - 2's kernel reads: the upload stream waits for that kernel, on the device
         if (c >= 2) VDYN_PIPE(hipStreamWaitEvent(h->stage_stream, h->ev_kernel[b], 0));
-        VDYN_PIPE(hipMemcpyAsync(dev_ctrl[b], pin_ctrl[b], bytes, hipMemcpyHostToDevice, h->stage_stream));
+        VDYN_PIPE(hipMemcpyAsync(dev + o_ctrl[b], pin + o_ctrl[b], bytes, hipMemcpyHostToDevice, h->stage_stream));
         VDYN_PIPE(hipEventRecord(h->ev_h2d[b], h->stage_stream));
         // (the upload stream is in order: chunk 0's event also covers the state upload queued before it)
         VDYN_PIPE(hipStreamWaitEvent(h->stream, h->ev_h2d[b], 0));
+        if (a.traj)
+            if (int rc = down.before_kernel(c)) return drain(rc);
         vdyn::RolloutArgs<T> ac = a;
         ac.H = (int)hn;
         ac.state0 = dev_state[b];
         ac.terminal = dev_state[b ^ 1];
-        ac.ctrl = reinterpret_cast<const T *>(dev_ctrl[b]);
-        ac.traj = a.traj ? dev_traj + (size_t)traj_row * 12 * (size_t)a.n : nullptr;
+        ac.ctrl = reinterpret_cast<const T *>(dev + o_ctrl[b]);
+        ac.traj = a.traj ? reinterpret_cast<T *>(dev + o_traj[b]) : nullptr;
         if (int rc = rollout_dev<T>(h, ac, h->stream, who)) return drain(rc);
         VDYN_PIPE(hipEventRecord(h->ev_kernel[b], h->stream));
-        if (a.traj) traj_row += hn / a.traj_stride;
+        if (a.traj) {
+            // this chunk's trajectory rows go down while the next chunk is integrated; the chunk before is copied out
+            const size_t nrows = (size_t)(hn / a.traj_stride);
+            if (int rc = down.after_kernel(c, {{0, nrows * 12 * e, reinterpret_cast<char *>(a.traj) + (size_t)traj_row * 12 * e}}))
+                return drain(rc);
+            traj_row += (int64_t)nrows;
+        }
     }
-    VDYN_PIPE(hipMemcpyAsync(pin_term, dev_state[c & 1], rows * e, hipMemcpyDeviceToHost, h->stream));
-    if (a.traj && traj_bytes) VDYN_PIPE(hipMemcpyAsync(pin_traj, dev_traj, traj_bytes, hipMemcpyDeviceToHost, h->stream));
+    VDYN_PIPE(hipMemcpyAsync(pin + o_state[1], dev_state[c & 1], rows * e, hipMemcpyDeviceToHost, h->stream));
+    if (a.traj)
+        if (int rc = down.finish(c)) return drain(rc);
+    VDYN_PIPE(hipStreamSynchronize(h->stream));
+    h->host_copy(a.terminal, pin + o_state[1], rows * e);
+    return VDYN_OK;
+}
+
+// The closed loop's logs are the host ABI's other large transfer, downwards: the 45-column DataLog of 65536 vehicles x 100
+// sub-steps is 1.2 GB for a 0.2 ms kernel.  The horizon is cut at multiples of ctrl_every (launches chained there repeat
+// the single launch's log rows bit for bit: include/vdyn.h; tests/test_gpu_parity.py holds the kernels to it) and the
+// chunks' rows stream out through the Downloader while the next chunk runs; state and controller state go from launch to
+// launch on the device.
+template <typename T>
+int closed_loop_host_pipelined(VdynHandle *h, const VdynCtrlGains *g, vdyn::ClosedLoopArgs<T> a, int64_t hc)
+{
+    const size_t e = sizeof(T) * (size_t)a.n;
+    const size_t wp_bytes = sizeof(T) * (size_t)a.P * a.Wmax * 2, wc_bytes = sizeof(int32_t) * (size_t)a.P,
+                 pid_bytes = sizeof(int32_t) * (size_t)a.n;
+    Layout L;                                                   // inputs first: one upload covers them
+    const size_t o_s0 = L.add(12 * e), o_c0 = L.add(6 * e), o_wp = L.add(wp_bytes), o_wc = L.add(wc_bytes), o_pid = L.add(pid_bytes);
+    const size_t in_end = L.total;
+    const size_t o_s1 = L.add(12 * e), o_c1 = L.add(6 * e);
+    const size_t log_chunk = a.log ? (size_t)hc * 16 * e : 0, dl_chunk = a.datalog ? (size_t)hc * 45 * e : 0;
+    const size_t o_rows[2] = {L.add(log_chunk + 256 + dl_chunk), L.add(log_chunk + 256 + dl_chunk)};
+    const size_t dl_off = (log_chunk + 255) & ~(size_t)255;     // DataLog rows behind the log rows inside a chunk buffer
+    if (int rc = ensure_scratch(h, L.total, L.total)) return rc;
+    if (int rc = ensure_pipeline(h)) return rc;
+    char *pin = static_cast<char *>(h->h_pinned), *dev = static_cast<char *>(h->d_scratch);
+    auto drain = [&](int rc) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->down_stream);
+        return rc;
+    };
+    h->host_copy(pin + o_s0, a.state0, 12 * e);
+    h->host_copy(pin + o_c0, a.cstate0, 6 * e);
+    h->host_copy(pin + o_wp, a.wp, wp_bytes);
+    h->host_copy(pin + o_wc, a.wcount, wc_bytes);
+    h->host_copy(pin + o_pid, a.path_id, pid_bytes);
+    VDYN_PIPE(hipMemcpyAsync(dev, pin, in_end, hipMemcpyHostToDevice, h->stream));
+    T *dstate[2] = {reinterpret_cast<T *>(dev + o_s0), reinterpret_cast<T *>(dev + o_s1)};
+    T *dcs[2] = {reinterpret_cast<T *>(dev + o_c0), reinterpret_cast<T *>(dev + o_c1)};
+    Downloader down(h, dev + o_rows[0], dev + o_rows[1], pin + o_rows[0], pin + o_rows[1]);
+    int64_t t0 = 0;
+    int c = 0;
+    for (int64_t hn = 0; t0 < a.H; t0 += hn, ++c) {
+        const int b = c & 1;
+        // the first chunk ends where (phase + t) is next a multiple of ctrl_every, every later one spans whole periods
+        hn = c == 0 ? hc - (a.phase % a.ctrl_every + a.ctrl_every) % a.ctrl_every : hc;
+        if (hn <= 0) hn = hc;
+        hn = std::min<int64_t>(hn, a.H - t0);
+        if (int rc = down.before_kernel(c)) return drain(rc);
+        vdyn::ClosedLoopArgs<T> ac = a;
+        ac.H = (int)hn;
+        ac.phase = a.phase + (int)t0;
+        ac.state0 = dstate[b];
+        ac.cstate0 = dcs[b];
+        ac.terminal = dstate[b ^ 1];
+        ac.cstate = dcs[b ^ 1];
+        ac.wp = reinterpret_cast<const T *>(dev + o_wp);
+        ac.wcount = reinterpret_cast<const int *>(dev + o_wc);
+        ac.path_id = reinterpret_cast<const int *>(dev + o_pid);
+        ac.log = a.log ? reinterpret_cast<T *>(dev + o_rows[b]) : nullptr;
+        ac.datalog = a.datalog ? reinterpret_cast<T *>(dev + o_rows[b] + dl_off) : nullptr;
+        if (int rc = closed_loop_dev<T>(h, g, ac, false, h->stream)) return drain(rc);
+        VDYN_PIPE(hipEventRecord(h->ev_kernel[b], h->stream));
+        std::vector<Downloader::Seg> segs;
+        if (a.log) segs.push_back({0, (size_t)hn * 16 * e, reinterpret_cast<char *>(a.log) + (size_t)t0 * 16 * e});
+        if (a.datalog) segs.push_back({dl_off, (size_t)hn * 45 * e, reinterpret_cast<char *>(a.datalog) + (size_t)t0 * 45 * e});
+        if (int rc = down.after_kernel(c, segs)) return drain(rc);
+    }
+    // terminal and controller state: into the pinned regions of the inputs (uploaded long ago)
+    VDYN_PIPE(hipMemcpyAsync(pin + o_s0, dstate[c & 1], 12 * e, hipMemcpyDeviceToHost, h->stream));
+    VDYN_PIPE(hipMemcpyAsync(pin + o_c0, dcs[c & 1], 6 * e, hipMemcpyDeviceToHost, h->stream));
+    if (int rc = down.finish(c)) return drain(rc);
     VDYN_PIPE(hipStreamSynchronize(h->stream));
 #undef VDYN_PIPE
-    h->host_copy(a.terminal, pin_term, rows * e);
-    if (a.traj && traj_bytes) h->host_copy(a.traj, pin_traj, traj_bytes);
+    h->host_copy(a.terminal, pin + o_s0, 12 * e);
+    h->host_copy(a.cstate, pin + o_c0, 6 * e);
     return VDYN_OK;
 }
 
@@ -1117,6 +1272,14 @@ int closed_loop_host(VdynHandle *h, const VdynCtrlGains *g, vdyn::ClosedLoopArgs
     int rc = closed_loop_check<T>(h, g, a, update_only, who);
     if (rc || a.n == 0) return rc;
     const size_t e = sizeof(T) * (size_t)a.n;
+    const size_t row_bytes = (a.log ? 16 * e : 0) + (a.datalog ? 45 * e : 0);
+    if (!update_only && row_bytes > 0 && a.ctrl_every >= 1 && (size_t)a.H * row_bytes >= kPipelineMinBytes) {
+        // chunks of whole controller periods, 2 .. 16 MB of log rows each; at least two of them
+        const size_t want = std::min<size_t>(std::max<size_t>((size_t)a.H * row_bytes / 12, 2u << 20), 16u << 20);
+        const int64_t ce = a.ctrl_every;
+        const int64_t hc = std::max<int64_t>(ce, (int64_t)(want / row_bytes) / ce * ce);
+        if (hc < a.H) return closed_loop_host_pipelined<T>(h, g, a, hc);
+    }
     Stage s(h);
     const size_t i0 = s.in(a.state0, 12 * e), i1 = s.in(a.cstate0, 6 * e),
                  i2 = s.in(a.wp, sizeof(T) * (size_t)a.P * a.Wmax * 2),

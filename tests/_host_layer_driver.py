@@ -242,22 +242,44 @@ def main():
         # ---- closed loop / controller update: log, datalog optional
         g = L.VdynCtrlGains()
         lib.vdyn_ctrl_gains_default(C.byref(g))
-        for n, H, P, Wmax, log, dl in ((1, 1, 1, 2, True, True), (100, 10, 7, 50, False, False), (65, 20, 3, 1024, True, False), (65, 4, 3, 9, False, True)):
+        big_rows = (8 << 20) // (45 * 4)                    # vehicles x sub-steps beyond which the log download is pipelined
+        for n, H, P, Wmax, log, dl, phase in ((1, 1, 1, 2, True, True, 0), (100, 10, 7, 50, False, False, 0), (65, 20, 3, 1024, True, False, 7),
+                                              (65, 4, 3, 9, False, True, 10), (big_rows // 23 + 5, 23, 2, 6, True, True, 3),
+                                              (big_rows // 9 + 1, 9, 1, 4, False, True, 0)):
             st, cs = ints((12, n), dtype=dtype), ints((6, n), dtype=dtype)
-            wp, wc, pid = ints((P, Wmax, 2), dtype=dtype), np.full(P, Wmax, np.int32), rng.integers(0, P, n).astype(np.int32)
+            wp, wc, pid = ints((P, Wmax, 2), -1, 2, dtype=dtype), np.full(P, Wmax, np.int32), rng.integers(0, P, n).astype(np.int32)
             term, cso = np.zeros((12, n), dtype), np.zeros((6, n), dtype)
             lg = np.zeros((H, 16, n), dtype) if log else None
             dlg = np.zeros((H, 45, n), dtype) if dl else None
-            rc = getattr(lib, f"vdyn_closed_loop_{sfx}_host")(h, C.byref(g), n, H, 10, 0, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
+            rc = getattr(lib, f"vdyn_closed_loop_{sfx}_host")(h, C.byref(g), n, H, 10, phase, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
                                                               vp(term), vp(cso), vp(lg), vp(dlg))
             check(rc == OK, f"closed_loop: {rc} {err(h)}")
-            base = float(st.sum() + cs.sum() + wp.sum() + wc.sum() + pid.sum())
-            same(term.ravel(), pattern(12 * n, base, dtype), "closed_loop terminal")
-            same(cso.ravel(), pattern(6 * n, base + 1, dtype), "closed_loop cstate")
+            # closed form of the stub's toy closed loop (hip_stub.cpp, closed_loop_body)
+            wsum = wp.astype(np.float64).reshape(P, -1).sum(axis=1)[pid]
+            s64, c64 = st.astype(np.float64), cs.astype(np.float64)
+            wlog, wdl, last = [], [], np.full(n, -1.0)
+            for t in range(H):
+                u = (phase + t) + wsum
+                s64 = s64 + np.arange(1, 13)[:, None] * u[None, :]
+                if (phase + t) % 10 == 0:
+                    c64 = c64 + np.arange(1, 7)[:, None] * u[None, :]
+                    last = u
+                if log:
+                    row = s64[np.arange(16) % 12] + np.arange(16)[:, None]
+                    row[15] = last                          # not carried between launches: -1 until ONE launch's first update
+                    wlog.append(row)
+                if dl:
+                    row = s64[np.arange(45) % 12] + 100 + np.arange(45)[:, None]
+                    row[44] = last
+                    wdl.append(row)
+            what = f"closed_loop {sfx} n={n} H={H} phase={phase}"
+            same(term, s64.astype(dtype), what + " terminal")
+            same(cso, c64.astype(dtype), what + " cstate")
             if log:
-                same(lg.ravel(), pattern(lg.size, base + 3, dtype), "closed_loop log")
+                same(lg, np.stack(wlog).astype(dtype), what + " log")
             if dl:
-                same(dlg.ravel(), pattern(dlg.size, base + 4, dtype), "closed_loop datalog")
+                same(dlg, np.stack(wdl).astype(dtype), what + " datalog")
+            base = float(st.sum() + cs.sum() + wp.sum() + wc.sum() + pid.sum())
             co = np.zeros((3, n), dtype)
             rc = getattr(lib, f"vdyn_controller_update_{sfx}_host")(h, C.byref(g), n, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
                                                                     vp(cso), vp(co))

@@ -646,16 +646,48 @@ void closed_loop_body(const ClosedLoopArgs<T> &a, bool update_only)
 {
     const size_t n = (size_t)a.n;
     if (a.aux) std::memset(a.aux, 0x22, closed_loop_aux_bytes<T>(a.P, a.Wmax, update_only));
-    const double base = read_all(a.state0, 12 * n) + read_all(a.cstate0, 6 * n) + read_all(a.wp, (size_t)a.P * a.Wmax * 2) +
-                        read_all(a.wcount, (size_t)a.P) + read_all(a.path_id, n);
-    write_all(a.cstate, 6 * n, base + 1);
     if (update_only) {
+        const double base = read_all(a.state0, 12 * n) + read_all(a.cstate0, 6 * n) + read_all(a.wp, (size_t)a.P * a.Wmax * 2) +
+                            read_all(a.wcount, (size_t)a.P) + read_all(a.path_id, n);
+        write_all(a.cstate, 6 * n, base + 1);
         write_all(a.ctrl_out, 3 * n, base + 2);
-    } else {
-        write_all(a.terminal, 12 * n, base);
-        write_all(a.log, (size_t)a.H * 16 * n, base + 3);
-        write_all(a.datalog, (size_t)a.H * 45 * n, base + 4);
+        return;
     }
+    // a toy closed loop with the REAL kernel's chaining property -- launches of H1 then H2 sub-steps with the phase carried
+    // (phase, phase + H1) and the state / controller state fed back ARE one launch of H1 + H2, log rows included:
+    //   per sub-step t, vehicle r:  u = (phase + t) + sum(wp[path r]);  state[i] += (i + 1) u;
+    //   controller state[j] += (j + 1) u on the sub-steps the controllers fire, (phase + t) % ctrl_every == 0;
+    //   log[t][c] = state[c % 12] + c,  datalog[t][c] = state[c % 12] + 100 + c   (after the sub-step), except the LAST column
+    //   of each: the u of the launch's most recent controller update, -1 before its first -- like the real log's target
+    //   index, NOT carried from launch to launch, so only cuts at multiples of ctrl_every reproduce the single launch
+    read_all(a.wcount, (size_t)a.P);
+    std::vector<double> wsum((size_t)a.P);
+    for (int p = 0; p < a.P; ++p) wsum[p] = read_all(a.wp + (size_t)p * a.Wmax * 2, (size_t)a.Wmax * 2);
+    std::vector<double> s(12 * n), cs(6 * n);
+    for (size_t i = 0; i < 12 * n; ++i) s[i] = (double)a.state0[i];
+    for (size_t i = 0; i < 6 * n; ++i) cs[i] = (double)a.cstate0[i];
+    std::vector<double> last(n, -1.0);
+    for (int t = 0; t < a.H; ++t) {
+        const bool fire = (a.phase + t) % a.ctrl_every == 0;
+        for (size_t r = 0; r < n; ++r) {
+            const int p = std::min(std::max(a.path_id[r], 0), a.P - 1);
+            const double u = (double)(a.phase + t) + wsum[p];
+            for (int i = 0; i < 12; ++i) s[(size_t)i * n + r] += (i + 1) * u;
+            if (fire) {
+                for (int j = 0; j < 6; ++j) cs[(size_t)j * n + r] += (j + 1) * u;
+                last[r] = u;
+            }
+        }
+        if (a.log)
+            for (int c = 0; c < 16; ++c)
+                for (size_t r = 0; r < n; ++r) a.log[((size_t)t * 16 + c) * n + r] = (T)(c == 15 ? last[r] : s[(size_t)(c % 12) * n + r] + c);
+        if (a.datalog)
+            for (int c = 0; c < 45; ++c)
+                for (size_t r = 0; r < n; ++r)
+                    a.datalog[((size_t)t * 45 + c) * n + r] = (T)(c == 44 ? last[r] : s[(size_t)(c % 12) * n + r] + 100 + c);
+    }
+    for (size_t i = 0; i < 12 * n; ++i) a.terminal[i] = (T)s[i];
+    for (size_t i = 0; i < 6 * n; ++i) a.cstate[i] = (T)cs[i];
 }
 }  // namespace
 template <typename T>

@@ -241,6 +241,34 @@ def test_host_abi_pipelined_per_rollout_controls_equal_the_device_abi_bitwise(gp
                           vm.rollout(s0d[:, :100].contiguous(), cd[:, :, :100].contiguous()).cpu().numpy())
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_host_abi_closed_loop_logs_stream_out_in_chunks_bitwise(gpu_vm, workloads, dtype):
+    """The closed loop's logs through the host-pointer ABI ([H][16][n] and the 45-column DataLog [H][45][n]: 55 MB and
+    more here) leave in chunks of whole controller periods -- chunk c's rows cross PCIe and are copied out by the worker
+    threads while chunk c + 1 is integrated, state and controller state chained on the device
+    (closed_loop_host_pipelined, csrc/vdyn_capi.hip) -- and must equal the device ABI's single launch bit for bit: every
+    log row, also with a start phase that is no multiple of the period (the first chunk then ends at the next
+    multiple), terminal and controller state."""
+    import torch
+    n, H = 6000, 57
+    st, cs, wp, wc, pid = workloads.closed_loop_config(n, dtype=dtype, seed=3)
+    vm = gpu_vm(1e-3)
+    dev = torch.device("cuda:0")
+    dargs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (st, cs, wp)]
+    wcd, pidd = torch.from_numpy(wc).to(dev), torch.from_numpy(pid).to(dev)
+    for phase, every in ((0, 10), (13, 10), (4, 7)):
+        wt, wc_, wlog = (x.cpu().numpy() for x in vm.closed_loop(*dargs, H, wcount=wcd, path_id=pidd, log=True, phase=phase,
+                                                                ctrl_every=every))
+        _, _, wdl = (x.cpu().numpy() for x in vm.closed_loop(*dargs, H, wcount=wcd, path_id=pidd, datalog=True, phase=phase,
+                                                             ctrl_every=every))
+        gt, gc, glog = vm.closed_loop(st, cs, wp, H, wcount=wc, path_id=pid, log=True, phase=phase, ctrl_every=every)
+        assert isinstance(glog, np.ndarray) and glog.nbytes > 8 << 20
+        assert np.array_equal(gt, wt) and np.array_equal(gc, wc_), f"phase {phase}: terminal / controller state"
+        assert np.array_equal(glog, wlog, equal_nan=True), f"phase {phase}, every {every}: log rows"
+        gt2, gc2, gdl = vm.closed_loop(st, cs, wp, H, wcount=wc, path_id=pid, datalog=True, phase=phase, ctrl_every=every)
+        assert np.array_equal(gdl, wdl, equal_nan=True) and np.array_equal(gt2, wt) and np.array_equal(gc2, wc_), f"phase {phase}: DataLog"
+
+
 def test_fp32_long_horizon_1000_steps(gpu_vm, oracle, workloads):
     """fp32 rounding grows with the horizon (the state accumulation at |x| ~ 100 m rounds at 4e-6 per step):
     a 1000-step rollout (1 s) of 4096 config-3 rollouts against the fp64 oracle, row-relative and element-wise."""
