@@ -558,6 +558,8 @@ int rollout_dev(VdynHandle *h, const vdyn::RolloutArgs<T> &a, void *stream, cons
     if (a.traj && a.traj_stride <= 0) return h->fail(VDYN_ERR_ARG, w + ": traj needs traj_stride > 0");
     if (a.traj && !row_writer_fits<T>(a.n, 12))
         return h->fail(VDYN_ERR_ARG, w + ": a trajectory row (12 n values) must not exceed 2^31 bytes; split the batch");
+    if ((a.state_dot || a.outputs) && a.layout != VDYN_CTRL_PER_ROLLOUT)
+        return h->fail(VDYN_ERR_ARG, w + ": diagnostics (state_dot / outputs) come with per-rollout controls");
     VDYN_HIP(h, hipSetDevice(h->device));
     vdyn::RolloutArgs<T> b = a;
     b.state_rows = h->state_rows;

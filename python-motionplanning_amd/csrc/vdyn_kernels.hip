@@ -1802,14 +1802,22 @@ static hipError_t launch_rollout_impl(const VdynParams &p, const RolloutArgs<T> 
         chunk = (int)std::min<size_t>((size_t)chunk, kLdsBudget / per_step);
         lds = (size_t)chunk * per_step;
     }
-    if (a.traj != nullptr || DIAG)
+    // (`if constexpr`: a diagnostic launch exists in the TRAJ form only -- the other form would be an instance nobody can
+    // launch, and the fp64 k = 12 ones are the heaviest kernels of the library to compile)
+    if constexpr (DIAG) {
         hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true, PW, COMP>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
                            a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
                            a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
-    else
-        hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false, PW, COMP>), dim3(grid), dim3(kBlock), lds, st, P, a.n,
-                           a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
-                           a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
+    } else {
+        if (a.traj != nullptr)
+            hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, true, PW, COMP>), dim3(grid), dim3(kBlock), lds, st, P,
+                               a.n, a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                               a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
+        else
+            hipLaunchKernelGGL((rollout_kernel<T, K, LAYOUT, DIAG, CS, false, PW, COMP>), dim3(grid), dim3(kBlock), lds, st, P,
+                               a.n, a.H, a.state0, a.ctrl, a.path_id, a.P, chunk, (T)a.dt, a.terminal, a.traj,
+                               a.traj_stride > 0 ? a.traj_stride : 1, a.state_dot, a.outputs);
+    }
     return hipGetLastError();
 }
 
@@ -1937,10 +1945,15 @@ hipError_t launch_rollout(const VdynParams &p, const RolloutArgs<T> &a, hipStrea
         VDYN_DISPATCH_Q(12, 2)
 #undef VDYN_DISPATCH_Q
     }
-    // the diagnostic (single-step drop-in) variants are launch-latency bound: general form only
+    // the diagnostic (single-step drop-in) variants are launch-latency bound: general form only, and per-rollout controls
+    // only -- diagnostics come in through vdyn_step_* (one step, controls [k][n]); a shared table with diagnostics is
+    // refused by the C ABI (rollout_dev), so those instances are not built
 #define VDYN_DISPATCH(KK, LL)                                                          \
     if (a.k == KK && layout == LL) {                                                   \
-        if (diag) return launch_rollout_impl<T, KK, LL, true, false>(p, a, st);        \
+        if (diag) {                                                                    \
+            if constexpr (LL == 0) return launch_rollout_impl<T, KK, LL, true, false>(p, a, st); \
+            else return hipErrorInvalidValue;                                          \
+        }                                                                              \
         if constexpr (sizeof(T) == 8)                                                  \
             if (pw) return axles ? launch_rollout_impl<T, KK, LL, false, true, 2>(p, a, st) \
                                  : launch_rollout_impl<T, KK, LL, false, true, 1>(p, a, st); \
