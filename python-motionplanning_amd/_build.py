@@ -22,8 +22,10 @@ LIB_PATH = os.environ.get("VDYN_LIB_PATH") or os.path.join(PKG_DIR, "libvdyn_hip
 # under iterative-ilp (configs[1] 1.02 -> 0.86 ms) -- hence one translation unit per precision.  Re-measured with
 # the fitted tire chain (round 2, one box): headline max-ilp 0.1536-0.1542 ms, iterative-ilp 0.1542, default
 # (max-occupancy) 0.1548, iterative-minreg 0.1713; closed loop 0.317 / 0.330 / 0.313 / 0.390.
-SOURCES = [("vdyn_kernels_f32.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
-           ("vdyn_kernels_f64.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
+SOURCES = [("vdyn_kernels_f64_rollout.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),     # the longest first
+           ("vdyn_kernels_f32_rollout.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+           ("vdyn_kernels_f64_rest.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
+           ("vdyn_kernels_f32_rest.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
            ("vdyn_capi.hip", [])]
 HEADERS = [os.path.join(CSRC, h) for h in ("vdyn_kernels.hip", "vdyn_device.hpp", "vdyn_internal.hpp",
                                            "vdyn_fastmath.hpp", "vdyn_packed.hpp", "vdyn_controls.hpp",

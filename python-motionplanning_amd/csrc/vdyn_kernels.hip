@@ -2274,8 +2274,15 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     return hipGetLastError();
 }
 
-#define VDYN_INSTANTIATE(T)                                                                          \
-    template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);  \
+// The explicit instantiations, in two parts per precision: VDYN_PART 1 = the rollout launcher (lane and wheel-parallel
+// kernels: more than half of the library's kernels and the heaviest to compile), VDYN_PART 2 = everything else; no
+// VDYN_PART = both.  Four translation units (vdyn_kernels_f32_rollout.hip, ..._f32_rest.hip, ..._f64_rollout.hip,
+// ..._f64_rest.hip) compile in parallel, each precision with the instruction-scheduling strategy that suits it
+// (_build.py).  Everything a part does not instantiate it only declares; file-local state (the tire-fit cache) simply
+// exists once per part.
+#define VDYN_INSTANTIATE_ROLLOUT(T)                                                                  \
+    template hipError_t launch_rollout<T>(const VdynParams &, const RolloutArgs<T> &, hipStream_t);
+#define VDYN_INSTANTIATE_REST(T)                                                                     \
     template hipError_t launch_rollout_spiral<T>(const VdynParams &, int64_t, int, const T *, const T *, double, \
                                                  double, double, double, const double *, T *, T *, int, hipStream_t); \
     template hipError_t launch_nonfinite_lanes<T>(int, int64_t, const T *, int *, unsigned long long *, hipStream_t); \
@@ -2296,15 +2303,27 @@ hipError_t launch_interpolate_waypoints(int E, int P, int L, const T *paths, con
     template hipError_t launch_plan_lattice<T>(const LatticeArgs<T> &, hipStream_t);                 \
     template hipError_t launch_interpolate_waypoints<T>(int, int, int, const T *, const int *, double, int, T *, \
                                                         int *, hipStream_t);
-// One translation unit per precision (vdyn_kernels_f32.hip / _f64.hip include this file): they
-// compile in parallel and with the instruction-scheduling strategy that suits each (_build.py).
+#if !defined(VDYN_PART) || VDYN_PART == 1
+#define VDYN_INSTANTIATE_1(T) VDYN_INSTANTIATE_ROLLOUT(T)
+#else
+#define VDYN_INSTANTIATE_1(T)
+#endif
+#if !defined(VDYN_PART) || VDYN_PART == 2
+#define VDYN_INSTANTIATE_2(T) VDYN_INSTANTIATE_REST(T)
+#else
+#define VDYN_INSTANTIATE_2(T)
+#endif
 #if !defined(VDYN_ONLY_F64)
-VDYN_INSTANTIATE(float)
+VDYN_INSTANTIATE_1(float)
+VDYN_INSTANTIATE_2(float)
+#if !defined(VDYN_PART) || VDYN_PART == 2
 bool tire_fit_coefficients(double C, float *coef) { return fit_tire_wheel<float, kTireFitDeg>(C, coef, kTireFitTol32); }
 bool tire_fit_coefficients64(double C, double *coef) { return fit_tire_wheel<double, kTireFitDeg64>(C, coef, kTireFitTol64); }
 #endif
+#endif
 #if !defined(VDYN_ONLY_F32)
-VDYN_INSTANTIATE(double)
+VDYN_INSTANTIATE_1(double)
+VDYN_INSTANTIATE_2(double)
 #endif
 
 }  // namespace vdyn

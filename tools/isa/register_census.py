@@ -4,7 +4,7 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -fno-slp-vectorize \\
           -mllvm -amdgpu-sched-strategy=iterative-ilp -I python-motionplanning_amd/csrc -S --cuda-device-only \\
-          python-motionplanning_amd/csrc/vdyn_kernels_f64.hip -o /tmp/f64_all.s        # ~2.5 min
+          python-motionplanning_amd/csrc/vdyn_kernels_f64_rollout.hip   # (or ..._f64_rest.hip) -o /tmp/f64_all.s        # ~2.5 min
     python3 tools/isa/register_census.py /tmp/f64_all.s [kernel-substring] [--all]
 
 Without --all only kernels with scratch or spills are listed.  `vspill` counts VGPRs the allocator parked (in AGPRs

@@ -5,7 +5,7 @@ instructions and accumulator moves per kernel, and per loop of the kernels that 
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -fno-slp-vectorize \\
           -mllvm -amdgpu-sched-strategy=iterative-ilp -I python-motionplanning_amd/csrc -S --cuda-device-only \\
-          python-motionplanning_amd/csrc/vdyn_kernels_f64.hip -o /tmp/f64_all.s        # ~2 min
+          python-motionplanning_amd/csrc/vdyn_kernels_f64_rollout.hip   # (or ..._f64_rest.hip) -o /tmp/f64_all.s        # ~2 min
     python3 tools/isa/spill_census.py /tmp/f64_all.s [kernel-substring]
 """
 import os
