@@ -393,8 +393,11 @@ def supervise(args, argv, script):
         except (OSError, ValueError):
             return None
 
-    def attempt(k, child_argv, env_extra, timeout_s):
-        """Run this rank's worker of attempt k to its end (bounded).  -> (exit code, held result line or None)"""
+    def attempt(k, child_argv, env_extra, timeout_s, annotate=None):
+        """Run this rank's worker of attempt k to its end (bounded).  -> (exit code, result line or None, printed?).
+        A line with a measured headline goes out THE MOMENT rank 0's worker writes it (with `annotate` merged in): whatever
+        happens to the worker afterwards -- a closing barrier with a lost peer -- cannot take it back or delay it.  A line
+        without a value is held: the decision about a second attempt comes first."""
         env = dict(os.environ)
         env.update({"VDYN_BENCH_WORKER": "1", "VDYN_BENCH_ATTEMPT": str(k),
                     "VDYN_BENCH_ABORT_FILE": os.path.join(cdir, f"a{k}.failed")})
@@ -413,16 +416,21 @@ def supervise(args, argv, script):
         proc = subprocess.Popen(cmd, env={a: b for a, b in env.items() if b is not None}, preexec_fn=die_with_parent,
                                 stdout=subprocess.PIPE if rank == 0 else None, text=True if rank == 0 else None)
         current["proc"] = proc
-        held = []
+        held, printed = [], []
 
         def pump():
             for ln in proc.stdout:
                 d = _is_result_line(ln.strip())
-                if d is not None:
-                    held.append(d)          # the ONE line is printed by this supervisor, after the decision
-                else:
+                if d is None:
                     sys.stdout.write(ln)
                     sys.stdout.flush()
+                elif d.get("value") is not None and not printed:
+                    d.update(annotate or {})
+                    print(json.dumps(d), flush=True)
+                    printed.append(True)
+                    held.append(d)
+                else:
+                    held.append(d)          # no headline in it: printed by this supervisor after the decision, if at all
 
         th = None
         if rank == 0:
@@ -443,7 +451,7 @@ def supervise(args, argv, script):
             th.join(timeout=5)
         if rc != 0:
             put(f"a{k}.failed")
-        return rc, (held[-1] if held else None)
+        return rc, (held[-1] if held else None), bool(printed)
 
     # SIGTERM / SIGINT to a supervisor (torch.distributed.run ending the job) go on to its worker before it leaves
     import signal
@@ -472,15 +480,13 @@ def supervise(args, argv, script):
                 "warmup": args.warmup, "higher_is_better": True, "error": why}
 
     # ---- attempt 1: the command as typed ------------------------------------------------------------------------
-    rc1, line1 = attempt(1, argv, {}, args.run_timeout_s)
+    rc1, line1, out1 = attempt(1, argv, {}, args.run_timeout_s)
     can_relaunch = (not args.no_relaunch and not args.no_peer_copies and args.exchange in ("auto", "p2p"))
     if rank == 0:
-        measured = line1 is not None and line1.get("value") is not None
-        if measured:
+        if out1:                            # the measured line is already out
             put("a1.decision", {"action": "done"})
             if rc1 != 0:
-                line1["rank0_exit_code"] = rc1
-            print(json.dumps(line1), flush=True)
+                sys.stderr.write(f"[bench.py] supervisor of rank 0: the line is out; the worker then ended with code {rc1}\n")
             return 0
         l1 = line1 or {}
         first = {"after": rc1, "first_attempt_stage": l1.get("timed_out_in") or l1.get("failed_in"),
@@ -526,17 +532,21 @@ def supervise(args, argv, script):
     sys.stderr.write(f"[bench.py] supervisor of rank {rank}: first attempt ended with code {rc1} and no measured "
                      f"headline; starting a fresh rank with --exchange rccl (port {dec['port']})\n")
     # a rendezvous of its own: rank 0 of the new set hosts the store (the agent's store still holds the first set's keys)
-    rc2, line2 = attempt(2, argv2, {"MASTER_PORT": str(dec["port"]), "TORCHELASTIC_USE_AGENT_STORE": None},
-                         dec["run_timeout_s"])
+    rc2, line2, out2 = attempt(2, argv2, {"MASTER_PORT": str(dec["port"]), "TORCHELASTIC_USE_AGENT_STORE": None},
+                               dec["run_timeout_s"], annotate={"relaunched": first} if rank == 0 else None)
     if rank != 0:
         # the outcome is rank 0's to report: a non-zero exit here would make the agent tear down rank 0's supervisor
         # before it has printed the line
+        return 0
+    if out2:
+        if rc2 != 0:
+            sys.stderr.write(f"[bench.py] supervisor of rank 0: the line is out; the second worker then ended with code {rc2}\n")
         return 0
     line = line2 or line1 or stub_line(f"rank 0 ended with codes {rc1}, {rc2} without a line")
     first["second_attempt_exit_code"] = rc2
     line["relaunched"] = first
     print(json.dumps(line), flush=True)
-    return 0 if line.get("value") is not None else (rc2 or EXIT_WATCHDOG)
+    return rc2 or EXIT_WATCHDOG
 
 
 def total_rollouts(world, per_gpu, strong):

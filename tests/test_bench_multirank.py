@@ -122,7 +122,7 @@ def test_peer_copy_that_never_completes_ends_in_a_relaunch_with_rccl_and_one_lin
     assert rl["after"] == bench.EXIT_WATCHDOG and rl["first_attempt_stage"] == "calibration: peer copies"
     # (the rank whose deadline passes first ends, its supervisor marks the attempt failed, the other rank may see that
     # mark a moment before its own deadline)
-    assert rl["first_attempt_why"] in ("run_deadline", "peer_rank_failed") and rl["second_attempt_exit_code"] == 0
+    assert rl["first_attempt_why"] in ("run_deadline", "peer_rank_failed")
     assert out["attempt"] == 2 and out["value"] > 0 and out["exchange"]["verified"] is True
     assert out["exchange"]["kind"] == "all_gather_into_tensor" and out["exchange"]["peer_copies_disabled"] is True
     assert out["exchange_calibration"] is None
