@@ -1263,6 +1263,41 @@ def extra_configs(vm, W, torch, dev, s0, tab, pid):
         "copy_threads": os.environ.get("VDYN_COPY_THREADS", "default: min(8, usable CPUs / 2)"),
         "bar": "<= 1.3 x the pinned one-shot upload of the same bytes (VERDICT round 4, item 4)"}
     del pin, dst, ctrl_h
+    # ... and the host ABI's large OUTPUT: the 45-column DataLog of 65536 vehicles x 100 sub-steps, 1.18 GB, into a
+    # caller-owned (already touched) NumPy array through the raw C ABI -- chunks of whole controller periods stream out
+    # while the next chunk runs (closed_loop_host_pipelined).  Beside it the floor: those bytes from the device into
+    # pinned memory in one copy.
+    import ctypes as C_
+    L_ = importlib.import_module("python-motionplanning_amd._lib")
+    st_h, cs_h, wp_h, wc_h, pidc_h = W.closed_loop_config(N_PER_GPU, dtype=np.float32)
+    g_ = L_.default_ctrl_gains()
+    term_h, cso_h = np.zeros((12, N_PER_GPU), np.float32), np.zeros((6, N_PER_GPU), np.float32)
+    dl_h = np.zeros((100, 45, N_PER_GPU), np.float32)
+    vp_ = lambda a: C_.c_void_p(a.ctypes.data)
+    hh = vm.handle()
+    call_dl = lambda: hh.call("vdyn_closed_loop_f32_host", C_.byref(g_), N_PER_GPU, 100, 10, 0, vp_(st_h), vp_(cs_h), vp_(wp_h),
+                              wp_h.shape[1], vp_(wc_h), vp_(pidc_h), wp_h.shape[0], DT, vp_(term_h), vp_(cso_h), None, vp_(dl_h))
+    call_dl()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        call_dl()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    pin = torch.empty(dl_h.size, dtype=torch.float32).pin_memory()
+    dsrc = torch.empty(dl_h.size, dtype=torch.float32, device=dev)
+    pin.copy_(dsrc, non_blocking=True)
+    torch.cuda.synchronize()
+    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a_.record()
+    pin.copy_(dsrc, non_blocking=True)
+    b_.record()
+    torch.cuda.synchronize()
+    t_pin = a_.elapsed_time(b_) * 1e-3
+    ex["host_abi_closed_loop_datalog_f32"] = {"ms": t * 1e3, "GB_out": dl_h.nbytes / 1e9, "GBs": dl_h.nbytes / t / 1e9,
+                                              "pinned_d2h_ms": t_pin * 1e3, "pinned_d2h_GBs": dl_h.nbytes / t_pin / 1e9,
+                                              "ratio_to_pinned_d2h": t / t_pin, "vehicle_sub_steps_per_s": N_PER_GPU * 100 / t}
+    del pin, dsrc, dl_h
     # two independent batches in flight: launches alternate between two HIP streams (one handle each),
     # so the next batch's dispatch, table staging and first loads overlap the tail of the previous one
     # and the two waves a SIMD then holds run out of phase (tools/two_stream_probe.py)
