@@ -140,6 +140,17 @@ def main():
             H = 40 if k == 2 else 29
             n = big // (H * k * np.dtype(dtype).itemsize) + 3
             run_rollout(h, sfx, dtype, n, H, k, False, stride)
+        # ---- a seeded random sweep around the staging decisions: control bytes just under / over the pipelining threshold,
+        # two- and three-step horizons, strides that do not divide the horizon or exceed half of it (whole-buffer path)
+        thr = 8 << 20
+        for _ in range(14):
+            k = int(rng.choice([2, 12]))
+            H = int(rng.choice([2, 3, 5, 16, 31]))
+            itemsize = np.dtype(dtype).itemsize
+            n_thr = thr // (H * k * itemsize)
+            n = max(1, int(n_thr + rng.integers(-3, 4)) if rng.integers(0, 2) else int(rng.integers(1, 700)))
+            stride = int(rng.choice([0, 0, 1, 2, H // 2 + 1, H, H + 1]))
+            run_rollout(h, sfx, dtype, n, H, k, False, stride)
         for lanes in (4, 0):                                # wheel-parallel kernel; 0 = chosen by the batch size
             check(lib.vdyn_set_option(h, L.VDYN_OPT_LANES_PER_ROLLOUT, lanes) == OK, "set lanes")
             run_rollout(h, sfx, dtype, 200, 8, 2, False, 2)
