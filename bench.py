@@ -272,7 +272,9 @@ class Watchdog:
     thread was in goes into the line (`timed_out_in`) and, for every rank, onto stderr.  Exit code EXIT_WATCHDOG:
     os._exit from the timer thread, because the main thread may be blocked inside a collective or a HIP call for good."""
 
-    IMPORT_ALLOWANCE_S = 180.0      # the first `import torch` on a fresh box pages the image in: 1-2 minutes, not a hang
+    # the first `import torch` on a fresh box pages the image in: 1-2 minutes, not a hang.  (The launcher gives its second
+    # attempt a shorter one -- the pages are in by then -- so that both attempts stay inside --total-budget-s.)
+    IMPORT_ALLOWANCE_S = float(os.environ.get("VDYN_BENCH_IMPORT_ALLOWANCE_S", "180"))
 
     def __init__(self, rank, out, run_timeout_s, abort_file=None, poll_s=0.25):
         import threading
@@ -393,7 +395,7 @@ def supervise(args, argv, script):
         except (OSError, ValueError):
             return None
 
-    def attempt(k, child_argv, env_extra, timeout_s, annotate=None):
+    def attempt(k, child_argv, env_extra, timeout_s, annotate=None, import_allowance_s=None):
         """Run this rank's worker of attempt k to its end (bounded).  -> (exit code, result line or None, printed?).
         A line with a measured headline goes out THE MOMENT rank 0's worker writes it (with `annotate` merged in): whatever
         happens to the worker afterwards -- a closing barrier with a lost peer -- cannot take it back or delay it.  A line
@@ -436,12 +438,13 @@ def supervise(args, argv, script):
         if rank == 0:
             th = threading.Thread(target=pump, daemon=True)
             th.start()
+        hard = timeout_s + (Watchdog.IMPORT_ALLOWANCE_S if import_allowance_s is None else import_allowance_s) + grace
         try:
-            rc = proc.wait(timeout=timeout_s + Watchdog.IMPORT_ALLOWANCE_S + grace)
+            rc = proc.wait(timeout=hard)
         except subprocess.TimeoutExpired:
             # its own watchdog did not end it (blocked where not even os._exit gets through, or stopped): kill it
             sys.stderr.write(f"[bench.py] supervisor of rank {rank}: attempt {k} worker still alive "
-                             f"{timeout_s + Watchdog.IMPORT_ALLOWANCE_S + grace:.0f} s after its start; killing it\n")
+                             f"{hard:.0f} s after its start; killing it\n")
             proc.kill()
             try:
                 rc = proc.wait(timeout=10)
@@ -494,8 +497,9 @@ def supervise(args, argv, script):
                  or ("exception: " + l1["error"] if l1.get("error") else "rank 0 ended without a line"),
                  "first_attempt_s": time.time() - t_launch}
         left = args.total_budget_s - (time.time() - t_launch) - grace - 5.0
-        t2 = min(args.run_timeout_s, left)
-        if not can_relaunch or left < 30.0:
+        imp2 = max(10.0, min(60.0, left / 3.0))         # torch is in the page cache by now
+        t2 = min(args.run_timeout_s, left - imp2)
+        if not can_relaunch or left < 45.0:
             put("a1.decision", {"action": "give_up"})
             line = line1 or stub_line(f"rank 0 ended with code {rc1} without a line")
             line["relaunched"] = None
@@ -504,8 +508,8 @@ def supervise(args, argv, script):
             print(json.dumps(line), flush=True)
             return rc1 or EXIT_WATCHDOG
         port2 = free_port()
-        put("a1.decision", {"action": "relaunch", "port": port2, "run_timeout_s": t2})
-        dec = {"action": "relaunch", "port": port2, "run_timeout_s": t2}
+        dec = {"action": "relaunch", "port": port2, "run_timeout_s": t2, "import_allowance_s": imp2}
+        put("a1.decision", dec)
     else:
         # rank 0's supervisor decides after ITS worker ended, which its watchdog bounds
         dec = wait_decision(1, args.run_timeout_s + Watchdog.IMPORT_ALLOWANCE_S + 2 * grace + 30.0)
@@ -532,8 +536,10 @@ def supervise(args, argv, script):
     sys.stderr.write(f"[bench.py] supervisor of rank {rank}: first attempt ended with code {rc1} and no measured "
                      f"headline; starting a fresh rank with --exchange rccl (port {dec['port']})\n")
     # a rendezvous of its own: rank 0 of the new set hosts the store (the agent's store still holds the first set's keys)
-    rc2, line2, out2 = attempt(2, argv2, {"MASTER_PORT": str(dec["port"]), "TORCHELASTIC_USE_AGENT_STORE": None},
-                               dec["run_timeout_s"], annotate={"relaunched": first} if rank == 0 else None)
+    rc2, line2, out2 = attempt(2, argv2, {"MASTER_PORT": str(dec["port"]), "TORCHELASTIC_USE_AGENT_STORE": None,
+                                          "VDYN_BENCH_IMPORT_ALLOWANCE_S": f"{dec['import_allowance_s']:.1f}"},
+                               dec["run_timeout_s"], annotate={"relaunched": first} if rank == 0 else None,
+                               import_allowance_s=dec["import_allowance_s"])
     if rank != 0:
         # the outcome is rank 0's to report: a non-zero exit here would make the agent tear down rank 0's supervisor
         # before it has printed the line
