@@ -105,6 +105,7 @@ def parse(argv=None):
     # set by the launcher for the second attempt: nothing touches the peer-copy exchange (auto -> rccl, `exchange_ab`
     # skips p2p, `strong` runs over the all-gather)
     ap.add_argument("--no-peer-copies", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-rollouts", type=int, default=N_PER_GPU, help=argparse.SUPPRESS)   # tests: a smaller sample
     return ap.parse_args(argv)
 
 
@@ -139,7 +140,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None):
+def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None, n_rollouts=N_PER_GPU):
     """The oracle (oracle/, the checker -- never the product) timed on this host:
     kind 'port'.  Bounded sample of the bench workload, sized for ~10-30 core-seconds.
     ``gpu_terminal`` ([12][N] fp32, the bench kernel's own output): its error against the fp64
@@ -149,7 +150,7 @@ def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None):
     O.build()
     p = O.default_params()
     threads = min(O.max_threads(), usable_cores())
-    s0, tab, pid = W.config3(N_PER_GPU, HORIZON, np.float32)
+    s0, tab, pid = W.config3(n_rollouts, HORIZON, np.float32)
     s0, tab = s0.astype(np.float64), tab.astype(np.float64)
     O.rollout(p, s0[:, :4096], tab, DT, path_id=pid[:4096], nthreads=threads)  # warm the pool
     reps, t_all = 0, 0.0
@@ -158,7 +159,7 @@ def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None):
         ref = O.rollout(p, s0, tab, DT, path_id=pid, nthreads=threads)
         reps += 1
         t_all = time.perf_counter() - t0
-    n1 = 8192                           # one core: 1/8 of the workload
+    n1 = min(8192, n_rollouts)          # one core: 1/8 of the workload
     t0 = time.perf_counter()
     O.rollout(p, s0[:, :n1], tab, DT, path_id=pid[:n1], nthreads=1)
     t_one = time.perf_counter() - t0
@@ -168,8 +169,9 @@ def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None):
     t0 = time.perf_counter()
     NB.rollout(NB.Params(), s0, tab[:, :10], DT, pid)
     t_np = time.perf_counter() - t0
+    full = n_rollouts == N_PER_GPU
     err = None
-    if gpu_terminal is not None:
+    if gpu_terminal is not None and full:            # (the error needs the oracle's result for the whole workload)
         ref = np.asarray(ref[0] if isinstance(ref, tuple) else ref)
         d = np.abs(gpu_terminal.astype(np.float64) - ref)
         scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)   # per state row
@@ -184,14 +186,14 @@ def cpu_baseline(W, gpu_terminal=None, gpu_terminal_comp=None):
                                             "max_rel_to_row_scale": float((dc / scale).max())}
     return {
         "fp32_state_error": err,
-        "value": reps * N_PER_GPU * HORIZON / t_all, "unit": "vehicle-steps/s", "cores": threads,
+        "value": reps * n_rollouts * HORIZON / t_all, "unit": "vehicle-steps/s", "cores": threads,
         "kind": "port",
-        "sample": f"fp64 C oracle (gcc -O2 -ffp-contract=off, OpenMP): {reps} x the full bench workload "
-                  f"(65536 rollouts x {HORIZON} steps) on {threads} threads in {t_all:.2f} s, plus {n1} "
+        "sample": f"fp64 C oracle (gcc -O2 -ffp-contract=off, OpenMP): {reps} x {'the full bench workload' if full else 'a part of the bench workload'} "
+                  f"({n_rollouts} rollouts x {HORIZON} steps) on {threads} threads in {t_all:.2f} s, plus {n1} "
                   f"rollouts x {HORIZON} steps on 1 thread in {t_one:.2f} s",
         "value_1core": n1 * HORIZON / t_one,
-        "numpy_vectorised": {"value": N_PER_GPU * 10 / t_np, "unit": "vehicle-steps/s",
-                             "sample": f"65536 rollouts x 10 steps as NumPy arrays in {t_np:.2f} s (one process)"},
+        "numpy_vectorised": {"value": n_rollouts * 10 / t_np, "unit": "vehicle-steps/s",
+                             "sample": f"{n_rollouts} rollouts x 10 steps as NumPy arrays in {t_np:.2f} s (one process)"},
         "reference_python_1core": 4.04e3,  # NumPy reference, measured in the build container only
     }
 
@@ -981,7 +983,7 @@ def _run(args, compute_factory, wd, out, world, rank, local_rank):
                     term_c = cp.vm.rollout(s22, job.tabd, path_id=job.pid)[:12].cpu().numpy()
             elif full_size and strong_full is not None:
                 gpu_term = strong_full
-            cb = cpu_baseline(W, gpu_term, term_c)
+            cb = cpu_baseline(W, gpu_term, term_c, n_rollouts=args.cpu_baseline_rollouts)
             err = cb.pop("fp32_state_error")
             if err is not None:
                 out["fp32_state_error"] = err

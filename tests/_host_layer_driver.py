@@ -32,6 +32,8 @@ OK, ERR_ARG, ERR_OOM = 0, -1, -4
 # level 2 (tests/hipstub/build_launchers.sh): the REAL launchers' host halves run, a launch is only checked for its
 # geometry and counted -- nothing is computed, so content checks are off and launch counts are checked instead
 LEVEL2 = os.environ.get("HIPSTUB_LEVEL") == "2"
+# HIPSTUB_QUICK: only the calls whose staging copies are large enough for the worker threads (the ThreadSanitizer run)
+QUICK = bool(os.environ.get("HIPSTUB_QUICK"))
 if LEVEL2:
     lib.hipstub_launch_count.restype, lib.hipstub_launch_count.argtypes = C.c_longlong, [C.c_char_p]
     lib.hipstub_distinct_kernels.restype = C.c_longlong
@@ -126,6 +128,55 @@ def run_rollout(h, sfx, dtype, n, H, k, shared, stride, rows=12, mu=None):
         same(traj, wtraj.astype(dtype), what + " trajectory")
 
 
+def closed_loop_cases(h, sfx, dtype):
+    # ---- closed loop / controller update: log, datalog optional
+    g = L.VdynCtrlGains()
+    lib.vdyn_ctrl_gains_default(C.byref(g))
+    big_rows = (8 << 20) // (45 * 4)                    # vehicles x sub-steps beyond which the log download is pipelined
+    for n, H, P, Wmax, log, dl, phase in ((1, 1, 1, 2, True, True, 0), (100, 10, 7, 50, False, False, 0), (65, 20, 3, 1024, True, False, 7),
+                                          (65, 4, 3, 9, False, True, 10), (big_rows // 23 + 5, 23, 2, 6, True, True, 3),
+                                          (big_rows // 9 + 1, 9, 1, 4, False, True, 0)):
+        st, cs = ints((12, n), dtype=dtype), ints((6, n), dtype=dtype)
+        wp, wc, pid = ints((P, Wmax, 2), -1, 2, dtype=dtype), np.full(P, Wmax, np.int32), rng.integers(0, P, n).astype(np.int32)
+        term, cso = np.zeros((12, n), dtype), np.zeros((6, n), dtype)
+        lg = np.zeros((H, 16, n), dtype) if log else None
+        dlg = np.zeros((H, 45, n), dtype) if dl else None
+        rc = getattr(lib, f"vdyn_closed_loop_{sfx}_host")(h, C.byref(g), n, H, 10, phase, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
+                                                          vp(term), vp(cso), vp(lg), vp(dlg))
+        check(rc == OK, f"closed_loop: {rc} {err(h)}")
+        # closed form of the stub's toy closed loop (hip_stub.cpp, closed_loop_body)
+        wsum = wp.astype(np.float64).reshape(P, -1).sum(axis=1)[pid]
+        s64, c64 = st.astype(np.float64), cs.astype(np.float64)
+        wlog, wdl, last = [], [], np.full(n, -1.0)
+        for t in range(H):
+            u = (phase + t) + wsum
+            s64 = s64 + np.arange(1, 13)[:, None] * u[None, :]
+            if (phase + t) % 10 == 0:
+                c64 = c64 + np.arange(1, 7)[:, None] * u[None, :]
+                last = u
+            if log:
+                row = s64[np.arange(16) % 12] + np.arange(16)[:, None]
+                row[15] = last                          # not carried between launches: -1 until ONE launch's first update
+                wlog.append(row)
+            if dl:
+                row = s64[np.arange(45) % 12] + 100 + np.arange(45)[:, None]
+                row[44] = last
+                wdl.append(row)
+        what = f"closed_loop {sfx} n={n} H={H} phase={phase}"
+        same(term, s64.astype(dtype), what + " terminal")
+        same(cso, c64.astype(dtype), what + " cstate")
+        if log:
+            same(lg, np.stack(wlog).astype(dtype), what + " log")
+        if dl:
+            same(dlg, np.stack(wdl).astype(dtype), what + " datalog")
+        base = float(st.sum() + cs.sum() + wp.sum() + wc.sum() + pid.sum())
+        co = np.zeros((3, n), dtype)
+        rc = getattr(lib, f"vdyn_controller_update_{sfx}_host")(h, C.byref(g), n, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
+                                                                vp(cso), vp(co))
+        check(rc == OK, f"controller_update: {rc} {err(h)}")
+        same(co.ravel(), pattern(3 * n, base + 2, dtype), "controller_update out")
+
+
 def main():
     h, p = create()
     check(lib.vdyn_abi_version() == L.VDYN_ABI_VERSION and lib.vdyn_build_id() == (b"hipstub2" if LEVEL2 else b"hipstub"), "abi / build id")
@@ -140,6 +191,9 @@ def main():
             H = 40 if k == 2 else 29
             n = big // (H * k * np.dtype(dtype).itemsize) + 3
             run_rollout(h, sfx, dtype, n, H, k, False, stride)
+        if QUICK:
+            closed_loop_cases(h, sfx, dtype)
+            continue
         # ---- a seeded random sweep around the staging decisions: control bytes just under / over the pipelining threshold,
         # two- and three-step horizons, strides that do not divide the horizon or exceed half of it (whole-buffer path)
         thr = 8 << 20
@@ -250,52 +304,7 @@ def main():
             same(bi, pattern(E, 0, np.int32), "mpc best_idx")
             if want_all:
                 same(ca.ravel(), pattern(E * Cn, base + 1, dtype), "mpc cost_all")
-        # ---- closed loop / controller update: log, datalog optional
-        g = L.VdynCtrlGains()
-        lib.vdyn_ctrl_gains_default(C.byref(g))
-        big_rows = (8 << 20) // (45 * 4)                    # vehicles x sub-steps beyond which the log download is pipelined
-        for n, H, P, Wmax, log, dl, phase in ((1, 1, 1, 2, True, True, 0), (100, 10, 7, 50, False, False, 0), (65, 20, 3, 1024, True, False, 7),
-                                              (65, 4, 3, 9, False, True, 10), (big_rows // 23 + 5, 23, 2, 6, True, True, 3),
-                                              (big_rows // 9 + 1, 9, 1, 4, False, True, 0)):
-            st, cs = ints((12, n), dtype=dtype), ints((6, n), dtype=dtype)
-            wp, wc, pid = ints((P, Wmax, 2), -1, 2, dtype=dtype), np.full(P, Wmax, np.int32), rng.integers(0, P, n).astype(np.int32)
-            term, cso = np.zeros((12, n), dtype), np.zeros((6, n), dtype)
-            lg = np.zeros((H, 16, n), dtype) if log else None
-            dlg = np.zeros((H, 45, n), dtype) if dl else None
-            rc = getattr(lib, f"vdyn_closed_loop_{sfx}_host")(h, C.byref(g), n, H, 10, phase, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
-                                                              vp(term), vp(cso), vp(lg), vp(dlg))
-            check(rc == OK, f"closed_loop: {rc} {err(h)}")
-            # closed form of the stub's toy closed loop (hip_stub.cpp, closed_loop_body)
-            wsum = wp.astype(np.float64).reshape(P, -1).sum(axis=1)[pid]
-            s64, c64 = st.astype(np.float64), cs.astype(np.float64)
-            wlog, wdl, last = [], [], np.full(n, -1.0)
-            for t in range(H):
-                u = (phase + t) + wsum
-                s64 = s64 + np.arange(1, 13)[:, None] * u[None, :]
-                if (phase + t) % 10 == 0:
-                    c64 = c64 + np.arange(1, 7)[:, None] * u[None, :]
-                    last = u
-                if log:
-                    row = s64[np.arange(16) % 12] + np.arange(16)[:, None]
-                    row[15] = last                          # not carried between launches: -1 until ONE launch's first update
-                    wlog.append(row)
-                if dl:
-                    row = s64[np.arange(45) % 12] + 100 + np.arange(45)[:, None]
-                    row[44] = last
-                    wdl.append(row)
-            what = f"closed_loop {sfx} n={n} H={H} phase={phase}"
-            same(term, s64.astype(dtype), what + " terminal")
-            same(cso, c64.astype(dtype), what + " cstate")
-            if log:
-                same(lg, np.stack(wlog).astype(dtype), what + " log")
-            if dl:
-                same(dlg, np.stack(wdl).astype(dtype), what + " datalog")
-            base = float(st.sum() + cs.sum() + wp.sum() + wc.sum() + pid.sum())
-            co = np.zeros((3, n), dtype)
-            rc = getattr(lib, f"vdyn_controller_update_{sfx}_host")(h, C.byref(g), n, vp(st), vp(cs), vp(wp), Wmax, vp(wc), vp(pid), P, 1e-3,
-                                                                    vp(cso), vp(co))
-            check(rc == OK, f"controller_update: {rc} {err(h)}")
-            same(co.ravel(), pattern(3 * n, base + 2, dtype), "controller_update out")
+        closed_loop_cases(h, sfx, dtype)
         # ---- select best path: obstacles shared / per ego / none; collision_in, validity optional
         off, rad = (C.c_double * 3)(-1.0, 1.0, 3.0), (C.c_double * 3)(1.5, 1.5, 1.5)
         for E, P, Lp, M, per_ego, cin, val in ((1, 1, 1, 0, 0, False, False), (10, 7, 49, 106, 0, False, True), (5, 64, 3, 4, 1, True, False)):
@@ -344,6 +353,11 @@ def main():
                     same(wp_out[e].ravel(), pattern(Wmax * 2, b2 + e, dtype), "interpolate table")
                     check(wcount[e] == Wmax, "interpolate count")
 
+    if QUICK:
+        lib.vdyn_destroy(h)
+        check(lib.hipstub_live_allocations() == 0 and lib.hipstub_live_streams_and_events() == 0, "leaks")
+        print(f"host layer driver (quick): {checks} checks passed")
+        return
     # ---- other tire sets: one C per axle, four different C, a shape factor no fit covers, a negative stiffness -- each takes
     # another way through the launchers (fit cache, per-wheel fit tables, the general chain); vdyn_set_params on a live handle
     def tires(**kw):

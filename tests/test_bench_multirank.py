@@ -84,7 +84,7 @@ def test_one_ulp_of_difference_in_a_peer_block_is_reported_as_unverified(tmp_pat
 def test_default_multirank_line_carries_the_cpu_baseline(tmp_path):
     """N > 1 without --no-cpu-baseline: rank 0 times the oracle on its host while the other ranks wait at the closing
     barrier; the line carries `cpu_baseline` as at N = 1 (no fp32 state error here: not the full-size workload)."""
-    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70"], cpu_baseline=True)
+    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--cpu-baseline-rollouts", "4096"], cpu_baseline=True)
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
     assert out["gpu_over_cpu"] > 0 and "fp32_state_error" not in out

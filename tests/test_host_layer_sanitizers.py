@@ -31,7 +31,7 @@ def asan_lib():
     return os.path.join(STUB, "_build", "libvdyn_capi_asan.so"), libasan
 
 
-@pytest.mark.parametrize("seed,threads", [(0, None), (1, "1"), (2, "3"), (3, "8")])
+@pytest.mark.parametrize("seed,threads", [(0, None), (1, "1"), (3, "8")])
 def test_every_host_entry_point_under_asan_ubsan(asan_lib, seed, threads):
     lib, libasan = asan_lib
     env = dict(os.environ, LD_PRELOAD=libasan, HIPSTUB_SEED=str(seed),
@@ -84,3 +84,22 @@ def test_real_launchers_host_halves_under_asan_ubsan():
     assert r.returncode == 0, tail
     assert "AddressSanitizer" not in tail and "runtime error" not in tail and "hipstub:" not in tail, tail
     assert "level 2:" in r.stdout and "distinct kernel instances" in r.stdout and "checks passed" in r.stdout
+
+
+def test_staging_worker_threads_under_tsan():
+    """The staging copies of the `_host` entry points run on worker threads (CopyPool, csrc/vdyn_capi.hip: a job posted
+    under a mutex, slices claimed through an atomic counter, the caller copying too).  The same driver, the same stub,
+    built with -fsanitize=thread and six copy threads: no data race may be reported."""
+    r = subprocess.run([os.path.join(STUB, "build.sh"), "tsan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    libtsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libtsan) or not os.path.exists(libtsan):
+        pytest.skip("gcc has no libtsan.so here")
+    env = dict(os.environ, LD_PRELOAD=libtsan, VDYN_COPY_THREADS="6", HIPSTUB_SEED="2", HIPSTUB_QUICK="1",
+               TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_host_layer_driver.py"),
+                        os.path.join(STUB, "_build", "libvdyn_capi_tsan.so")], capture_output=True, text=True, env=env,
+                       cwd=REPO, timeout=1200)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert "ThreadSanitizer" not in r.stderr and "data race" not in r.stderr, tail
+    assert r.returncode == 0 and "checks passed" in r.stdout, tail
