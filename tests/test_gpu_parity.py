@@ -269,6 +269,40 @@ def test_host_abi_closed_loop_logs_stream_out_in_chunks_bitwise(gpu_vm, workload
         assert np.array_equal(gdl, wdl, equal_nan=True) and np.array_equal(gt2, wt) and np.array_equal(gc2, wc_), f"phase {phase}: DataLog"
 
 
+def test_two_handles_on_two_threads_stage_independently(gpu_vm):
+    """A handle is single-threaded by contract; DISTINCT handles are independent (include/vdyn.h) -- each owns its streams,
+    events, staging buffers and staging worker threads.  Two Python threads, each with its own VehicleModel, run pipelined
+    host-ABI rollouts (ctypes releases the GIL for the call) at the same time: both must return what a lone call returns."""
+    import threading
+    rng = np.random.default_rng(77)
+    n, H = 20000, 60
+    s0 = np.zeros((12, n), np.float32)
+    s0[0] = rng.uniform(10, 30, n)
+    s0[3:7] = s0[0] / 0.308309813617345
+    s0[8:10] = rng.uniform(0, 100, (2, n))
+    ctrls = [np.stack([rng.uniform(-0.2, 0.2, (H, n)), rng.uniform(-100, 300, (H, n))], axis=1).astype(np.float32) for _ in range(2)]
+    assert ctrls[0].nbytes > 8 << 20
+    vms = [gpu_vm(1e-3), gpu_vm(1e-3)]
+    want = [vms[0].rollout(s0, c, traj_stride=3) for c in ctrls]
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                got[i] = vms[i].rollout(s0, ctrls[i], traj_stride=3)
+        except Exception as e:                      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1]), f"thread {i}"
+
+
 def test_fp32_long_horizon_1000_steps(gpu_vm, oracle, workloads):
     """fp32 rounding grows with the horizon (the state accumulation at |x| ~ 100 m rounds at 4e-6 per step):
     a 1000-step rollout (1 s) of 4096 config-3 rollouts against the fp64 oracle, row-relative and element-wise."""
