@@ -855,6 +855,7 @@ int planar_model_host(VdynHandle *h, int64_t n, const T *state, const T *ctrl12,
     return s.download();
 }
 
+// (Shared-table rollouts come through here too when their TRAJECTORY is large: the chunk's table is gathered on the host.)
 // Per-rollout controls [H][k][n] from host memory are the one _host input that is LARGE (105 MB at BASELINE configs[2],
 // against 3 MB of states): staged whole -- memcpy into pinned memory, one H2D copy, the kernel -- the call costs the sum
 // of the three.  Here the horizon is cut into chunks of whole steps (a chunk of [H][k][n] is one contiguous slab) that
@@ -950,7 +951,10 @@ template <typename T>
 int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
 {
     const size_t e = sizeof(T) * (size_t)a.n, rows = (size_t)h->state_rows;
-    const size_t step_bytes = (size_t)a.k * e;
+    // a step's controls: k rows of n values per rollout, or -- shared table [P][H][k] -- k values per path: a chunk's
+    // table [P][hn][k] is gathered from the caller's, path by path (it is small: what streams then is the trajectory)
+    const bool shared = a.layout == VDYN_CTRL_SHARED;
+    const size_t step_bytes = shared ? sizeof(T) * (size_t)a.P * a.k : (size_t)a.k * e;
     // what a step moves: its controls up and, with a trajectory, 12 rows down every traj_stride steps
     const size_t step_moves = step_bytes + (a.traj ? 12 * e / (size_t)a.traj_stride : 0);
     // chunk: about a twelfth of the horizon's bytes, 2 .. 16 MB, whole steps, a multiple of traj_stride.  The first two
@@ -971,6 +975,7 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
     const size_t o_state[2] = {L.add(rows * e), L.add(rows * e)};       // pinned: state0 | terminal; device: state A | state B
     const size_t o_ctrl[2] = {L.add(chunk_bytes), L.add(chunk_bytes)};
     const size_t o_traj[2] = {L.add(traj_chunk), L.add(traj_chunk)};
+    const size_t pid_bytes = shared ? sizeof(int32_t) * (size_t)a.n : 0, o_pid = L.add(pid_bytes);
     if (int rc = ensure_scratch(h, L.total, L.total)) return rc;
     if (int rc = ensure_pipeline(h)) return rc;
     char *pin = static_cast<char *>(h->h_pinned), *dev = static_cast<char *>(h->d_scratch);
@@ -988,6 +993,10 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
 
     h->host_copy(pin + o_state[0], a.state0, rows * e);
     VDYN_PIPE(hipMemcpyAsync(dev_state[0], pin + o_state[0], rows * e, hipMemcpyHostToDevice, h->stage_stream));
+    if (shared) {
+        h->host_copy(pin + o_pid, a.path_id, pid_bytes);
+        VDYN_PIPE(hipMemcpyAsync(dev + o_pid, pin + o_pid, pid_bytes, hipMemcpyHostToDevice, h->stage_stream));
+    }
     const char *src = reinterpret_cast<const char *>(a.ctrl);
     int64_t t0 = 0, traj_row = 0;
     int c = 0;
@@ -997,7 +1006,13 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
         const size_t bytes = (size_t)hn * step_bytes;
         // pinned ctrl[b] was the source of chunk c - 2's upload: that copy must have run before the host overwrites it
         if (c >= 2) VDYN_PIPE(hipEventSynchronize(h->ev_h2d[b]));
-        h->host_copy(pin + o_ctrl[b], src + (size_t)t0 * step_bytes, bytes);
+        if (shared) {
+            const size_t path_chunk = (size_t)hn * a.k * sizeof(T), path_full = (size_t)a.H * a.k * sizeof(T);
+            for (int p = 0; p < a.P; ++p)
+                std::memcpy(pin + o_ctrl[b] + (size_t)p * path_chunk, src + (size_t)p * path_full + (size_t)t0 * a.k * sizeof(T), path_chunk);
+        } else {
+            h->host_copy(pin + o_ctrl[b], src + (size_t)t0 * step_bytes, bytes);
+        }
         // device ctrl[b] is what chunk c - 2's kernel reads: the upload stream waits for that kernel, on the device
         if (c >= 2) VDYN_PIPE(hipStreamWaitEvent(h->stage_stream, h->ev_kernel[b], 0));
         VDYN_PIPE(hipMemcpyAsync(dev + o_ctrl[b], pin + o_ctrl[b], bytes, hipMemcpyHostToDevice, h->stage_stream));
@@ -1011,6 +1026,7 @@ int rollout_host_pipelined(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *wh
         ac.state0 = dev_state[b];
         ac.terminal = dev_state[b ^ 1];
         ac.ctrl = reinterpret_cast<const T *>(dev + o_ctrl[b]);
+        ac.path_id = shared ? reinterpret_cast<const int *>(dev + o_pid) : nullptr;
         ac.traj = a.traj ? reinterpret_cast<T *>(dev + o_traj[b]) : nullptr;
         if (int rc = rollout_dev<T>(h, ac, h->stream, who)) return drain(rc);
         VDYN_PIPE(hipEventRecord(h->ev_kernel[b], h->stream));
@@ -1119,9 +1135,11 @@ int rollout_host(VdynHandle *h, vdyn::RolloutArgs<T> a, const char *who)
     const size_t ctrl_bytes = a.layout == VDYN_CTRL_PER_ROLLOUT
                                   ? (size_t)a.H * a.k * e
                                   : sizeof(T) * (size_t)a.P * a.H * a.k;
-    if (a.layout == VDYN_CTRL_PER_ROLLOUT && a.H >= 2 && ctrl_bytes >= kPipelineMinBytes && !a.state_dot && !a.outputs &&
-        (!a.traj || a.traj_stride <= a.H / 2) && std::isfinite(a.dt) &&
-        !(h->state_rows != 12 && sizeof(T) != 4) && !(a.traj && !row_writer_fits<T>(a.n, 12)))
+    // large controls on the way in (per-rollout layout) or a large trajectory on the way out (either layout): in chunks
+    const bool big_in = a.layout == VDYN_CTRL_PER_ROLLOUT && ctrl_bytes >= kPipelineMinBytes;
+    const bool big_out = a.traj && (size_t)(a.H / a.traj_stride) * 12 * e >= kPipelineMinBytes;
+    if ((big_in || big_out) && a.H >= 2 && !a.state_dot && !a.outputs && (!a.traj || a.traj_stride <= a.H / 2) &&
+        std::isfinite(a.dt) && !(h->state_rows != 12 && sizeof(T) != 4) && !(a.traj && !row_writer_fits<T>(a.n, 12)))
         return rollout_host_pipelined<T>(h, a, who);
     Stage s(h);
     const size_t rows = (size_t)h->state_rows;

@@ -191,6 +191,10 @@ def main():
             H = 40 if k == 2 else 29
             n = big // (H * k * np.dtype(dtype).itemsize) + 3
             run_rollout(h, sfx, dtype, n, H, k, False, stride)
+        # shared table + a trajectory beyond 8 MB: the chunks' tables are gathered from the caller's [P][H][k]
+        nbig = (9 << 20) // (12 * np.dtype(dtype).itemsize * 20) + 7
+        run_rollout(h, sfx, dtype, nbig, 41, 2, True, 2)
+        run_rollout(h, sfx, dtype, nbig // 2, 40, 12, True, 1)
         if QUICK:
             closed_loop_cases(h, sfx, dtype)
             continue

@@ -303,6 +303,32 @@ def test_two_handles_on_two_threads_stage_independently(gpu_vm):
         assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1]), f"thread {i}"
 
 
+@pytest.mark.parametrize("dtype,k", [(np.float32, 2), (np.float64, 12)])
+def test_host_abi_shared_table_trajectory_streams_out_bitwise(gpu_vm, workloads, dtype, k):
+    """Lattice rollouts (controls shared per path, staged in LDS) with every state written, handed over and taken back as
+    NumPy arrays: 58 / 115 MB of trajectory leave in chunks while the next chunk is integrated -- each chunk's table
+    [P][hn][k] gathered on the host from the caller's [P][H][k] -- and must be the device ABI's single launch bit for bit,
+    at strides that do and do not divide the chunks, with a ragged batch."""
+    import torch
+    n, H, P = 20003, 60, 7
+    s0, tab2, pid = workloads.config3(n, H, dtype)
+    if k == 2:
+        tab = tab2
+    else:
+        rng = np.random.default_rng(5)
+        tab = np.concatenate([tab2[:, :, :1], tab2[:, :, :1], np.zeros((P, H, 2), dtype), np.repeat(tab2[:, :, 1:2], 4, axis=2),
+                              rng.uniform(0.8, 1.0, (P, H, 4)).astype(dtype)], axis=2)
+    tab = np.ascontiguousarray(tab)
+    dev = torch.device("cuda:0")
+    vm = gpu_vm(1e-3)
+    d = [torch.from_numpy(a).to(dev) for a in (s0, tab, pid)]
+    for stride in (1, 7):
+        wt, wtraj = (x.cpu().numpy() for x in vm.rollout(d[0], d[1], path_id=d[2], traj_stride=stride))
+        gt, gtraj = vm.rollout(s0, tab, path_id=pid, traj_stride=stride)
+        assert stride != 1 or gtraj.nbytes > 8 << 20                   # (stride 7, fp32: below the threshold, whole-buffer staging)
+        assert np.array_equal(gt, wt) and np.array_equal(gtraj, wtraj), f"stride {stride}"
+
+
 def test_fp32_long_horizon_1000_steps(gpu_vm, oracle, workloads):
     """fp32 rounding grows with the horizon (the state accumulation at |x| ~ 100 m rounds at 4e-6 per step):
     a 1000-step rollout (1 s) of 4096 config-3 rollouts against the fp64 oracle, row-relative and element-wise."""

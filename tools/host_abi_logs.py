@@ -1,7 +1,8 @@
 """GPU box: the two host-pointer calls whose OUTPUT is large, through the raw C ABI with caller-owned, already-touched
 output arrays (what the library itself spends; a fresh np.empty of 1.2 GB adds its page faults on top):
   * vdyn_closed_loop_f32_host with the 45-column DataLog, 65536 vehicles x 100 sub-steps: 1.18 GB out;
-  * vdyn_rollout_f32_host with per-rollout controls and every state written (traj_stride 1), 65536 x 200: 105 MB in, 629 MB out.
+  * vdyn_rollout_f32_host with per-rollout controls and every state written (traj_stride 1), 65536 x 200: 105 MB in, 629 MB out;
+  * the same with the controls as the lattice's shared table [7][200][2]: 629 MB out.
 usage: python tools/host_abi_logs.py            (VDYN_LIB_PATH selects another library build for an A/B)"""
 import ctypes as C
 import importlib
@@ -54,6 +55,9 @@ if __name__ == "__main__":
     med, best = timed(call)
     out["rollout_per_rollout_controls_traj1_65536x200_f32_host"] = {"ms": med, "ms_min": best, "GB_in": ctrl.nbytes / 1e9,
                                                                      "GB_out": traj.nbytes / 1e9}
+    call = lambda: h.call("vdyn_rollout_f32_host", n, 200, vp(s0), vp(tab), 2, 1, vp(pidr), tab.shape[0], 1e-3, None, vp(term), vp(traj), 1)
+    med, best = timed(call)
+    out["rollout_shared_table_traj1_65536x200_f32_host"] = {"ms": med, "ms_min": best, "GB_out": traj.nbytes / 1e9}
     import torch
     pin = torch.empty(traj.nbytes // 4, dtype=torch.float32).pin_memory()
     d = torch.empty(traj.nbytes // 4, dtype=torch.float32, device="cuda:0")
