@@ -127,7 +127,21 @@ class _Backend:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(x.shape)}")
         return x
 
-    def out(self, *shape, int32=False):
+    def out(self, *shape, int32=False, reuse=None):
+        """A fresh output buffer, or `reuse` -- the caller's own (same kind, dtype, shape, C-contiguous): a large host
+        array that lives across calls spares every call the page faults of a fresh np.empty (1.2 GB of DataLog is
+        290 000 pages)."""
+        if reuse is not None:
+            if self.torch:
+                ok = _is_torch_cuda(reuse) and reuse.device == self.device and reuse.is_contiguous() and \
+                    reuse.dtype == (self._t.int32 if int32 else self.t_dtype)
+            else:
+                ok = isinstance(reuse, np.ndarray) and reuse.flags.c_contiguous and reuse.flags.writeable and \
+                    reuse.dtype == (np.int32 if int32 else self.np_dtype)
+            if not ok or tuple(reuse.shape) != tuple(shape):
+                raise ValueError(f"out: need a writable C-contiguous {'tensor on the inputs device' if self.torch else 'ndarray'} "
+                                 f"of shape {tuple(shape)} and the call's dtype")
+            return reuse
         if self.torch:
             return self._t.empty(shape, dtype=self._t.int32 if int32 else self.t_dtype, device=self.device)
         return np.empty(shape, dtype=np.int32 if int32 else self.np_dtype)
@@ -303,13 +317,14 @@ class VehicleModel:
             _vp(ou), _vp(ac), *be.stream_args())
         return sd, aux, ou, ac
 
-    def rollout(self, states0, controls, dt=None, path_id=None, mu_max=None, traj_stride=0, p=None):
+    def rollout(self, states0, controls, dt=None, path_id=None, mu_max=None, traj_stride=0, p=None, out=None):
         """H zero-order-hold RK4 steps in one launch.
 
         ``states0 [12][N]``; ``controls [H][k][N]`` (per rollout) or, with
         ``path_id [N]``, a shared table ``[P][H][k]`` staged in LDS.
         Returns ``terminal [12][N]`` (and ``traj [H//traj_stride][12][N]`` when
-        ``traj_stride > 0``).
+        ``traj_stride > 0``).  ``out``: {"terminal", "traj"} -> the caller's own output buffers, written in
+        place and returned (a trajectory array that lives across calls spares each call its page faults).
 
         fp32 only: ``states0 [22][N]`` selects the compensated state sum (include/vdyn.h,
         VDYN_OPT_STATE_ROWS) -- rows 12..21 carry the compensation terms of rows 0..9 (zeros to start
@@ -343,8 +358,10 @@ class VehicleModel:
         if traj_stride < 0:
             raise ValueError("traj_stride must be >= 0")
         keep, mu4 = self._mu4(mu_max)
-        term = be.out(rows, n)
-        traj = be.out(H // traj_stride, 12, n) if traj_stride > 0 else None
+        # out: {"terminal": ..., "traj": ...} -- the caller's own output buffers, written in place and returned
+        out = out or {}
+        term = be.out(rows, n, reuse=out.get("terminal"))
+        traj = be.out(H // traj_stride, 12, n, reuse=out.get("traj")) if traj_stride > 0 else None
         h = self._handle(be.device_index(self.device), p)
         with h.lock:        # the row count is handle state: set, launch and reset as one step (see _lib.Handle.lock)
             if rows != 12:
@@ -494,20 +511,23 @@ class VehicleModel:
         return cso, out
 
     def closed_loop(self, states0, cstate0, waypoints, H, wcount=None, path_id=None, gains=None, dt=None,
-                    ctrl_every=10, phase=0, log=False, datalog=False):
+                    ctrl_every=10, phase=0, log=False, datalog=False, out=None):
         """H sub-steps of the reference's Car.drive loop (drive.py:114-151) minus the planner:
         controllers every ``ctrl_every`` steps (zero-order hold), RK4 every step.
         Returns ``terminal [12][N]``, ``cstate [6][N]`` (and ``log [H][16][N]``: state12, delta,
         torque, target index, crosstrack error; and/or ``datalog [H][45][N]``: the reference's
-        DataLog columns, drive.py:145-151 / plots.py:19-27, with t = (phase + step) * dt)."""
+        DataLog columns, drive.py:145-151 / plots.py:19-27, with t = (phase + step) * dt).
+        ``out``: {"terminal", "cstate", "log", "datalog"} -> the caller's own output buffers (any subset), written in
+        place and returned; worth it for the logs of a large fleet from NumPy memory (see ``_Backend.out``)."""
         be = _Backend(states0)
         st, n, cs, wp, P, Wmax, wc, pid = self._closed_loop_inputs(be, states0, cstate0, waypoints, wcount, path_id)
         if H < 0 or ctrl_every <= 0 or phase < 0:
             raise ValueError("need H >= 0, ctrl_every > 0, phase >= 0")
         g = gains if gains is not None else _lib.default_ctrl_gains()
-        term, cso = be.out(12, n), be.out(6, n)
-        lg = be.out(int(H), 16, n) if log else None
-        dl = be.out(int(H), 45, n) if datalog else None
+        out = out or {}
+        term, cso = be.out(12, n, reuse=out.get("terminal")), be.out(6, n, reuse=out.get("cstate"))
+        lg = be.out(int(H), 16, n, reuse=out.get("log")) if log else None
+        dl = be.out(int(H), 45, n, reuse=out.get("datalog")) if datalog else None
         self._handle(be.device_index(self.device)).call(
             f"vdyn_closed_loop_{be.suffix}_{be.kind}", C.byref(g), n, int(H), int(ctrl_every), int(phase),
             _vp(st), _vp(cs), _vp(wp), Wmax, _vp(wc), _vp(pid), P, float(self.dt if dt is None else dt),

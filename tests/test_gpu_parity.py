@@ -265,7 +265,9 @@ def test_host_abi_closed_loop_logs_stream_out_in_chunks_bitwise(gpu_vm, workload
         assert isinstance(glog, np.ndarray) and glog.nbytes > 8 << 20
         assert np.array_equal(gt, wt) and np.array_equal(gc, wc_), f"phase {phase}: terminal / controller state"
         assert np.array_equal(glog, wlog, equal_nan=True), f"phase {phase}, every {every}: log rows"
-        gt2, gc2, gdl = vm.closed_loop(st, cs, wp, H, wcount=wc, path_id=pid, datalog=True, phase=phase, ctrl_every=every)
+        mine = {"datalog": np.empty((H, 45, n), dtype), "terminal": np.empty((12, n), dtype)}
+        gt2, gc2, gdl = vm.closed_loop(st, cs, wp, H, wcount=wc, path_id=pid, datalog=True, phase=phase, ctrl_every=every, out=mine)
+        assert gdl is mine["datalog"] and gt2 is mine["terminal"]
         assert np.array_equal(gdl, wdl, equal_nan=True) and np.array_equal(gt2, wt) and np.array_equal(gc2, wc_), f"phase {phase}: DataLog"
 
 
@@ -327,6 +329,12 @@ def test_host_abi_shared_table_trajectory_streams_out_bitwise(gpu_vm, workloads,
         gt, gtraj = vm.rollout(s0, tab, path_id=pid, traj_stride=stride)
         assert stride != 1 or gtraj.nbytes > 8 << 20                   # (stride 7, fp32: below the threshold, whole-buffer staging)
         assert np.array_equal(gt, wt) and np.array_equal(gtraj, wtraj), f"stride {stride}"
+        # the caller's own output arrays, reused across calls (out=): written in place, returned as they are
+        mine = {"terminal": np.full_like(gt, 7), "traj": np.full_like(gtraj, 7)}
+        rt, rtraj = vm.rollout(s0, tab, path_id=pid, traj_stride=stride, out=mine)
+        assert rt is mine["terminal"] and rtraj is mine["traj"] and np.array_equal(rt, wt) and np.array_equal(rtraj, wtraj)
+    with pytest.raises(ValueError):
+        vm.rollout(s0, tab, path_id=pid, out={"terminal": np.zeros((12, n + 1), dtype)})
 
 
 def test_fp32_long_horizon_1000_steps(gpu_vm, oracle, workloads):
