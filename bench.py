@@ -397,6 +397,17 @@ def supervise(args, argv, script):
         except (OSError, ValueError):
             return None
 
+    # rank 0's supervisor prints ONE line, once: from the pump thread (a measured line), after a decision, or -- should the
+    # supervisor itself be told to go (SIGTERM from the agent tearing the job down) -- from the signal handler
+    emitted = threading.Lock()
+    last_held = {"line": None}
+
+    def emit_once(line):
+        if rank == 0 and emitted.acquire(blocking=False):
+            print(json.dumps(line), flush=True)
+            return True
+        return False
+
     def attempt(k, child_argv, env_extra, timeout_s, annotate=None, import_allowance_s=None):
         """Run this rank's worker of attempt k to its end (bounded).  -> (exit code, result line or None, printed?).
         A line with a measured headline goes out THE MOMENT rank 0's worker writes it (with `annotate` merged in): whatever
@@ -430,11 +441,12 @@ def supervise(args, argv, script):
                     sys.stdout.flush()
                 elif d.get("value") is not None and not printed:
                     d.update(annotate or {})
-                    print(json.dumps(d), flush=True)
+                    emit_once(d)
                     printed.append(True)
                     held.append(d)
                 else:
                     held.append(d)          # no headline in it: printed by this supervisor after the decision, if at all
+                    last_held["line"] = d
 
         th = None
         if rank == 0:
@@ -466,6 +478,10 @@ def supervise(args, argv, script):
         pr = current["proc"]
         if pr is not None and pr.poll() is None:
             pr.terminate()
+        if rank == 0:       # leave a line behind even now: what the worker said last, or why there is nothing
+            ln = last_held["line"] or stub_line(f"the launcher was ended by signal {signum} before rank 0 had a line")
+            ln.setdefault("terminated_by_signal", signum)
+            emit_once(ln)
         sys.exit(128 + signum)
 
     for sg in (signal.SIGTERM, signal.SIGINT):
@@ -502,12 +518,12 @@ def supervise(args, argv, script):
         imp2 = max(10.0, min(60.0, left / 3.0))         # torch is in the page cache by now
         t2 = min(args.run_timeout_s, left - imp2)
         if not can_relaunch or left < 45.0:
-            put("a1.decision", {"action": "give_up"})
             line = line1 or stub_line(f"rank 0 ended with code {rc1} without a line")
             line["relaunched"] = None
             line["not_relaunched_because"] = ("--no-relaunch / the peer copies were not in play" if not can_relaunch
                                               else f"{left:.0f} s of the budget left")
-            print(json.dumps(line), flush=True)
+            emit_once(line)                                     # the line first, the decision after it
+            put("a1.decision", {"action": "give_up"})
             return rc1 or EXIT_WATCHDOG
         port2 = free_port()
         dec = {"action": "relaunch", "port": port2, "run_timeout_s": t2, "import_allowance_s": imp2}
@@ -515,10 +531,10 @@ def supervise(args, argv, script):
     else:
         # rank 0's supervisor decides after ITS worker ended, which its watchdog bounds
         dec = wait_decision(1, args.run_timeout_s + Watchdog.IMPORT_ALLOWANCE_S + 2 * grace + 30.0)
-        if dec is None or dec["action"] == "give_up":
-            return rc1 or EXIT_WATCHDOG
-        if dec["action"] == "done":
-            return 0
+        if dec is None:
+            return rc1 or EXIT_WATCHDOG         # rank 0's supervisor is gone: nobody is left to report
+        if dec["action"] in ("done", "give_up"):
+            return 0                            # the outcome -- line and exit code -- is rank 0's supervisor's to report
     # ---- attempt 2: fresh ranks, the collective north_star names, no peer copies anywhere -----------------------
     argv2, skip = [], False
     for a in argv:
@@ -553,7 +569,7 @@ def supervise(args, argv, script):
     line = line2 or line1 or stub_line(f"rank 0 ended with codes {rc1}, {rc2} without a line")
     first["second_attempt_exit_code"] = rc2
     line["relaunched"] = first
-    print(json.dumps(line), flush=True)
+    emit_once(line)
     return rc2 or EXIT_WATCHDOG
 
 

@@ -215,12 +215,17 @@ def test_ending_the_launcher_ends_the_workers_too(tmp_path):
                 break
             time.sleep(0.5)
         assert len(workers) == 2, "two worker ranks expected under two supervisors"
+        workers.sort(key=lambda w: int(w.environ()["RANK"]))
         supervisors = [w.parent() for w in workers]
         time.sleep(3.0)                                                 # let them reach the hang
-        supervisors[1].send_signal(signal.SIGKILL)                      # a supervisor dies without a word ...
+        supervisors[1].send_signal(signal.SIGKILL)                      # rank 1's supervisor dies without a word ...
         top.send_signal(signal.SIGTERM)                                 # ... and the launcher is asked to stop
         gone, alive = psutil.wait_procs(workers + supervisors, timeout=60)
         assert not alive, f"left behind: {[(p.pid, p.cmdline()[-3:]) for p in alive]}"
+        # rank 0's supervisor, told to go by the agent (SIGTERM), still left ONE line behind: value null, and why
+        out, _ = top.communicate(timeout=60)
+        lines = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["terminated_by_signal"] == signal.SIGTERM, out[-2000:]
     finally:
         try:
             for p in psutil.Process(top.pid).children(recursive=True):
