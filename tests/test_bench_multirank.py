@@ -134,15 +134,17 @@ def test_peer_copy_that_never_completes_ends_in_a_relaunch_with_rccl_and_one_lin
         assert f"[bench.py] rank {r}: watchdog (" in out["_stderr"]
 
 
-def test_rank_that_raises_after_the_agree_step_ends_in_a_relaunch_without_waiting_out_the_deadline(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_that_raises_after_the_agree_step_ends_in_a_relaunch_without_waiting_out_the_deadline(tmp_path, world):
     """Rank 1 raises in try_create after the agree step (its peers have gone on to the next collective).  It ends
     non-zero; its supervisor marks the attempt failed; rank 0's watchdog sees the mark and ends rank 0 long before its
     200 s deadline; fresh ranks run over RCCL."""
     import time
     t0 = time.time()
-    out = _launch(tmp_path, 2, ["--rollouts-per-gpu", "70", "--run-timeout-s", "200"],
+    out = _launch(tmp_path, world, ["--rollouts-per-gpu", "70", "--run-timeout-s", "200"],
                   env_extra=dict(FAKE_P2P, VDYN_TEST_P2P_FAULT="raise_after_agree"))
-    assert time.time() - t0 < 150, "the surviving rank must not wait out its deadline"
+    assert time.time() - t0 < 150, "the surviving ranks must not wait out their deadline"
+    assert out["n_gpus"] == world and len(out["shards"]) == world
     rl = out["relaunched"]
     # rank 0 either saw the mark (a rank hung in an RCCL collective would) or its gloo collective raised when rank 1's
     # sockets closed: both leave a line with the stage behind
