@@ -6,10 +6,12 @@ launchers, whose "kernels" touch every byte their arguments promise) and driven 
 tests/_host_layer_driver.py in a child interpreter with libasan preloaded.  A stand-in for a library inside the product's
 own test: no oracle, no CPU path of the product.
 
-What the deferred stub is worth was checked once by hand (round 5): with any ONE of the pipelined upload's three
-dependencies removed -- the host waiting for chunk c - 2's upload before refilling its pinned buffer, the upload stream
-waiting for chunk c - 2's kernel before refilling its device buffer, the compute stream waiting for chunk c's upload --
-the driver fails under every seed tried."""
+What the deferred stub is worth: tests/hipstub/negative_experiments.sh removes, one at a time, six ordering dependencies
+of the upload / download pipelines from a copy of vdyn_capi.hip (the host waiting for chunk c - 2's upload before
+refilling its pinned buffer, the upload stream waiting for chunk c - 2's kernel, the compute stream waiting for chunk
+c's upload, the download waiting for the kernel, the host waiting for the download, the closed loop's first chunk ending
+at a controller period): the driver then fails under 4 of 4 seeds, every time (profiles/
+r05_host_layer_negative_experiments.txt; two and a half minutes, so not part of this suite)."""
 import os
 import subprocess
 import sys
